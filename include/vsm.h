@@ -1,0 +1,174 @@
+/*
+ * vsm — MI355X descriptor-matching engine, C ABI.
+ *
+ * The reference (thuanaislab/visual_slam) has no plugin or FFI interface on this
+ * path; its boundary is a set of file formats plus plain C++ calls that take
+ * caller-owned raw buffers.  Each entry point below names the reference code it
+ * stands in for.  Conventions follow the reference's own:
+ *   - caller allocates and frees every host buffer (FeaturePoints.cpp:516-531);
+ *   - readers return 1/0 or a count >= 0 (FeaturePoints.cpp:392,440; MatchFile.cpp:886);
+ *     everything else returns a count >= 0 or a negative VSM_E* code; nothing throws;
+ *   - a match list is two equal-length int32 arrays, image-0 index ascending and the
+ *     matching image-1 index, i.e. the two rows of Points<int>(NM, 2)
+ *     (MatchFile.h:55-65) and the two index lines of the match txt (main.py:114-155);
+ *   - dense results use -1 for "no match" (superglue.py:285-290);
+ *   - a context is single-threaded; distinct contexts may be used concurrently.
+ *
+ * All compute entry points require the HIP device the context was created on; there is
+ * no CPU fallback.
+ */
+#ifndef VSM_H
+#define VSM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSM_DESC_DIM_U8 128
+
+enum {
+    VSM_OK = 0,
+    VSM_EINVAL = -1,   /* bad argument */
+    VSM_ENODEV = -2,   /* no usable HIP device / HIP call failed */
+    VSM_ENOMEM = -3,   /* device or host allocation failed */
+    VSM_ECAP = -4,     /* caller buffer too small */
+    VSM_EIO = -5,      /* file error */
+    VSM_EFORMAT = -6,  /* malformed file */
+    VSM_EUNSUPPORTED = -7
+};
+
+enum { VSM_METRIC_DOT = 0, VSM_METRIC_L2 = 1 };
+enum { VSM_LAYOUT_ROWS = 0 /* [n][dim] */, VSM_LAYOUT_DIM_MAJOR = 1 /* [dim][n] */ };
+enum { VSM_NO_SECOND = INT32_MAX };
+
+typedef struct vsm_ctx vsm_ctx;
+
+typedef struct vsm_params {
+    int32_t ratio_num;     /* Lowe test on squared distances: accept iff d1*den^2 < num^2*d2; */
+    int32_t ratio_den;     /* num <= 0 disables it.  0 < num, den <= 16384.                    */
+    int32_t mutual;        /* keep (i, j) only if i is also the nearest image-0 row of j        */
+    int32_t reserved;
+    int64_t max_dist_sq;   /* u8 sets: accept iff d1 <= max_dist_sq; < 0 disables               */
+    float   min_score;     /* f32 DOT: accept iff best score > min_score                        */
+    float   max_dist_sq_f; /* f32 L2: accept iff d1 <= max_dist_sq_f; < 0 disables              */
+} vsm_params;
+
+/* ---- context -------------------------------------------------------------- */
+vsm_ctx* vsm_create(int device);
+void vsm_destroy(vsm_ctx* ctx);
+/* Message for the last failure on this context (or the last failed vsm_create
+ * when ctx is NULL).  Counterpart of the reference's redirectable printf
+ * (MatchFile.cpp:44-45, 62-65). */
+const char* vsm_last_error(const vsm_ctx* ctx);
+/* Blocks until all work queued by this context has finished. */
+int vsm_synchronize(vsm_ctx* ctx);
+/* Native stream handle (hipStream_t) the context launches on. */
+void* vsm_stream(vsm_ctx* ctx);
+
+/* ---- descriptor sets -------------------------------------------------------- */
+/* SIFT descriptors as FeatureData::ReadSIFTB(file, locbuf, desbuf, nmax) hands them
+ * over (FeaturePoints.cpp:516-531): row-major uint8 [n][128].  Returns a set id. */
+int vsm_upload_u8(vsm_ctx* ctx, const uint8_t* des, int n);
+/* Same, from a device pointer on the context's device (no host round trip). */
+int vsm_upload_u8_device(vsm_ctx* ctx, const void* des_dev, int n);
+/* SuperPoint-style float descriptors.  VSM_LAYOUT_DIM_MAJOR is the reference's
+ * native [256][N] tensor (superpoint.py:196-202), VSM_LAYOUT_ROWS the transposed
+ * form main.py:255 makes.  1 <= dim <= 256. */
+int vsm_upload_f32(vsm_ctx* ctx, const float* des, int n, int dim, int layout);
+int vsm_upload_f32_device(vsm_ctx* ctx, const void* des_dev, int n, int dim, int layout);
+int vsm_release_set(vsm_ctx* ctx, int set);
+int vsm_set_count(const vsm_ctx* ctx, int set);
+
+/* ---- matching ----------------------------------------------------------------- */
+/* One image pair: 2-NN of every set0 row in set1, ratio / distance / mutual tests,
+ * matches ascending in idx0.  The position the reference fills with
+ * matching(...) .. get_list_matching_pairs (main.py:241-273).  dist may be NULL
+ * (int32 squared L2 for u8 sets, float score/squared distance for f32 sets).
+ * Returns the match count, or VSM_ECAP if it exceeds cap. */
+int vsm_match_pair(vsm_ctx* ctx, int set0, int set1, const vsm_params* p, int metric,
+                   int32_t* idx0, int32_t* idx1, void* dist, int cap);
+/* Dense form: matches0[n0], matches1[n1] with -1 (superglue.py:276-293). */
+int vsm_match_pair_dense(vsm_ctx* ctx, int set0, int set1, const vsm_params* p, int metric,
+                         int32_t* matches0, int32_t* matches1);
+/* Many pairs in one submission (the per-pair loop of main.py:220-280).  pairs is
+ * [npairs][2] set ids.  offsets[npairs+1] receives where each pair's matches start
+ * in idx0/idx1 (cap entries each).  Returns the total or VSM_ECAP. */
+long long vsm_match_pairs(vsm_ctx* ctx, const int32_t* pairs, int npairs, const vsm_params* p,
+                          int metric, int64_t* offsets, int32_t* idx0, int32_t* idx1,
+                          long long cap);
+/* Same work, results left on the device; returns the total match count.  Fetch with
+ * vsm_fetch_matches before the next submission on this context. */
+long long vsm_match_pairs_device(vsm_ctx* ctx, const int32_t* pairs, int npairs,
+                                 const vsm_params* p, int metric);
+long long vsm_fetch_matches(vsm_ctx* ctx, int64_t* offsets, int32_t* idx0, int32_t* idx1,
+                            long long cap);
+
+/* ---- raw k-NN ------------------------------------------------------------------- */
+/* For every query row: nearest database row (lowest index on ties), its key, and the
+ * runner-up key.  u8: d1/d2 are int32 squared L2 (VSM_NO_SECOND when the database has
+ * one row).  f32: float; DOT keys are dot products (larger is better), L2 keys are
+ * squared distances.  idx2 may be NULL.  Brute-force 1-NN of
+ * NearestEmbedFunc.forward (model_2_0.py:43-78) is the k=1 part of this call. */
+int vsm_knn2(vsm_ctx* ctx, int set_q, int set_db, int metric,
+             int32_t* idx1, int32_t* idx2, void* d1, void* d2);
+/* Merge of per-slice vsm_knn2 results for a database cut into contiguous index
+ * ranges (slice s owns global rows [base[s], base[s+1])).  Inputs are host arrays
+ * [nslices][nq] with slice-local indices; outputs are global. */
+int vsm_merge_top2_f32(const float* k1, const float* k2, const int32_t* i1, const int32_t* i2,
+                       const int64_t* base, int nslices, int nq, int metric,
+                       float* ok1, float* ok2, int64_t* oi1, int64_t* oi2);
+/* NearestEmbedFunc.forward (model_2_0.py:43-78): x [batch][dim][npts], emb [dim][k];
+ * argmin [batch][npts] int64, result (may be NULL) [batch][dim][npts]. */
+int vsm_nearest_embed(vsm_ctx* ctx, const float* x, int batch, int dim, int npts,
+                      const float* emb, int k, int64_t* argmin, float* result);
+
+/* ---- measurement ----------------------------------------------------------------- */
+/* With timing on, the distance kernel of each submission is bracketed by HIP events on
+ * the context's stream; vsm_last_kernel_ms returns the last bracket (synchronises). */
+int vsm_set_timing(vsm_ctx* ctx, int on);
+float vsm_last_kernel_ms(vsm_ctx* ctx);
+
+/* ---- VisualSfM interchange files (host only, no device needed) ------------------- */
+/* FeatureData::ReadSIFTB(file, locbuf, desbuf, nmax) (FeaturePoints.cpp:516-531) with
+ * the header checks of the member reader (:388-446).  NULL buffers query the header.
+ * Returns the number of features stored in the file (0 on failure). */
+int vsm_sift_read(const char* path, float* locbuf, uint8_t* desbuf, int nmax,
+                  int* npoint, int* nloc_dim);
+/* FeatureData::saveSIFTB2 (FeaturePoints.cpp:228-280).  Returns 1/0. */
+int vsm_sift_write(const char* path, const float* loc, int nloc_dim,
+                   const uint8_t* des, int npoint);
+/* save_feature_locations (main.py:133-140) / ReadLocFromText (FeaturePoints.cpp:326-369). */
+int vsm_feature_txt_write(const char* path, const float* xy, int m);
+int vsm_feature_txt_read(const char* path, float* xy, int cap);
+/* get_list_matching_pairs + save_matching_sfm (main.py:114-155): appends one record
+ * built from the dense matches0[n] (-1 = none).  Returns the match count. */
+int vsm_matchtxt_append_dense(const char* path, const char* name0, const char* name1,
+                              const int32_t* matches0, int n);
+/* Same record from a match list; n0 is image 0's keypoint count (it decides the
+ * trailing-space quirk of main.py:124-129). */
+int vsm_matchtxt_append(const char* path, const char* name0, const char* name1,
+                        const int32_t* idx0, const int32_t* idx1, int nm, int n0);
+/* generate_imagePairs (main.py:157-169).  Returns the pair count. */
+int vsm_image_pairs(int nimages, int consecutive, const int32_t* discrete, int ndiscrete,
+                    int32_t* pairs, int cap);
+/* All i<j pairs (exhaustive matching).  Returns the pair count. */
+long long vsm_image_pairs_exhaustive(int nimages, int32_t* pairs, long long cap);
+/* MatchFile::WritePMatch(image1, image2, fc1, fc2, NM, matches) (MatchFile.cpp:751-832):
+ * image paths without extension; writes <image1>.mat and <image2>.mat.
+ * reservation = MatchFile::SetRecordReservation (MatchFile.h:244); pass 0 for the
+ * reference default of 20. */
+int vsm_mat_write_pmatch(const char* image1, const char* image2, int fc1, int fc2,
+                         int nm, const int32_t* idx1, const int32_t* idx2, int reservation);
+/* MatchFile(image).GetPMatch(other, FC, NM, matches) (MatchFile.cpp:856-895). */
+int vsm_mat_get_pmatch(const char* image, const char* other, int fc_other,
+                       int32_t* idx_this, int32_t* idx_other, int cap);
+/* MatchFile::GetMatchCount (MatchFile.cpp:938-958). Returns 1/0. */
+int vsm_mat_get_match_count(const char* image, const char* other, int* nm, int* nf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,190 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_PATH = os.path.join(_ROOT, "oracle", "liboracle.so")
+NO_SECOND = 2**31 - 1
+METRIC_DOT, METRIC_L2 = 0, 1
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("ratio_num", C.c_int32), ("ratio_den", C.c_int32), ("mutual", C.c_int32), ("reserved", C.c_int32),
+        ("max_dist_sq", C.c_int64), ("min_score", C.c_float), ("max_dist_sq_f", C.c_float),
+    ]
+
+
+def params(ratio=(4, 5), mutual=True, max_dist_sq=-1, min_score=float("-inf"), max_dist_sq_f=-1.0):
+    num, den = ratio if ratio else (0, 1)
+    return Params(num, den, 1 if mutual else 0, 0, max_dist_sq, min_score, max_dist_sq_f)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            raise RuntimeError("oracle not built: make -C oracle")
+        _lib = C.CDLL(_PATH)
+        _lib.orc_dot_f32.restype = C.c_float
+        _lib.orc_sift_write.restype = C.c_long
+        _lib.orc_matchtxt_record.restype = C.c_long
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+THREADS = min(8, os.cpu_count() or 1)
+
+
+def knn2_u8(A, B, threads=THREADS):
+    A = np.ascontiguousarray(A, np.uint8)
+    B = np.ascontiguousarray(B, np.uint8)
+    n, m = len(A), len(B)
+    idx = np.empty(max(n, 1), np.int32)
+    d1 = np.empty(max(n, 1), np.int32)
+    d2 = np.empty(max(n, 1), np.int32)
+    lib().orc_knn2_u8(_p(A), n, _p(B), m, threads, _p(idx), _p(d1), _p(d2))
+    return idx[:n], d1[:n], d2[:n]
+
+
+def colbest_u8(A, B, threads=THREADS):
+    A = np.ascontiguousarray(A, np.uint8)
+    B = np.ascontiguousarray(B, np.uint8)
+    n, m = len(A), len(B)
+    ci = np.empty(max(m, 1), np.int32)
+    cd = np.empty(max(m, 1), np.int32)
+    lib().orc_colbest_u8(_p(A), n, _p(B), m, threads, _p(ci), _p(cd))
+    return ci[:m], cd[:m]
+
+
+def match_u8(A, B, p, threads=THREADS):
+    A = np.ascontiguousarray(A, np.uint8)
+    B = np.ascontiguousarray(B, np.uint8)
+    n, m = len(A), len(B)
+    cap = max(n, 1)
+    i0 = np.empty(cap, np.int32)
+    i1 = np.empty(cap, np.int32)
+    d = np.empty(cap, np.int32)
+    nm = lib().orc_match_u8(_p(A), n, _p(B), m, C.byref(p), threads, _p(i0), _p(i1), _p(d), cap)
+    return i0[:nm], i1[:nm], d[:nm]
+
+
+def match_dense_u8(A, B, p, threads=THREADS):
+    A = np.ascontiguousarray(A, np.uint8)
+    B = np.ascontiguousarray(B, np.uint8)
+    n, m = len(A), len(B)
+    m0 = np.empty(max(n, 1), np.int32)
+    m1 = np.empty(max(m, 1), np.int32)
+    lib().orc_match_dense_u8(_p(A), n, _p(B), m, C.byref(p), threads, _p(m0), _p(m1))
+    return m0[:n], m1[:m]
+
+
+def knn2_f32(A, B, metric, threads=THREADS):
+    A = np.ascontiguousarray(A, np.float32)
+    B = np.ascontiguousarray(B, np.float32)
+    n, m, dim = len(A), len(B), A.shape[1]
+    idx = np.empty(max(n, 1), np.int32)
+    s1 = np.empty(max(n, 1), np.float32)
+    s2 = np.empty(max(n, 1), np.float32)
+    lib().orc_knn2_f32(_p(A), n, _p(B), m, dim, metric, threads, _p(idx), _p(s1), _p(s2))
+    return idx[:n], s1[:n], s2[:n]
+
+
+def colbest_f32(A, B, metric, threads=THREADS):
+    A = np.ascontiguousarray(A, np.float32)
+    B = np.ascontiguousarray(B, np.float32)
+    n, m, dim = len(A), len(B), A.shape[1]
+    ci = np.empty(max(m, 1), np.int32)
+    cs = np.empty(max(m, 1), np.float32)
+    lib().orc_colbest_f32(_p(A), n, _p(B), m, dim, metric, threads, _p(ci), _p(cs))
+    return ci[:m], cs[:m]
+
+
+def match_dense_f32(A, B, metric, p, threads=THREADS):
+    A = np.ascontiguousarray(A, np.float32)
+    B = np.ascontiguousarray(B, np.float32)
+    n, m, dim = len(A), len(B), A.shape[1]
+    m0 = np.empty(max(n, 1), np.int32)
+    m1 = np.empty(max(m, 1), np.int32)
+    b0 = np.empty(max(n, 1), np.float32)
+    b1 = np.empty(max(m, 1), np.float32)
+    lib().orc_match_dense_f32(_p(A), n, _p(B), m, dim, metric, C.byref(p), threads, _p(m0), _p(m1), _p(b0), _p(b1))
+    return m0[:n], m1[:m], b0[:n], b1[:m]
+
+
+def nearest_embed_f32(x, emb, threads=THREADS):
+    x = np.ascontiguousarray(x, np.float32)
+    emb = np.ascontiguousarray(emb, np.float32)
+    b, d = x.shape[0], x.shape[1]
+    npts = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
+    am = np.empty((b, npts), np.int64)
+    res = np.empty((b, d, npts), np.float32)
+    lib().orc_nearest_embed_f32(_p(x), b, d, npts, _p(emb), emb.shape[1], threads, _p(am), _p(res))
+    return res.reshape(x.shape), am.reshape((b,) + tuple(x.shape[2:]))
+
+
+def merge_top2_f32(k1, k2, i1, i2, metric):
+    k1 = np.ascontiguousarray(k1, np.float32)
+    k2 = np.ascontiguousarray(k2, np.float32)
+    i1 = np.ascontiguousarray(i1, np.int32)
+    i2 = np.ascontiguousarray(i2, np.int32)
+    ns, nq = k1.shape
+    ok1 = np.empty(nq, np.float32)
+    ok2 = np.empty(nq, np.float32)
+    oi1 = np.empty(nq, np.int32)
+    oi2 = np.empty(nq, np.int32)
+    lib().orc_merge_top2_f32(_p(k1), _p(k2), _p(i1), _p(i2), ns, nq, metric, _p(ok1), _p(ok2), _p(oi1), _p(oi2))
+    return ok1, ok2, oi1, oi2
+
+
+def sift_write(path, loc, des):
+    loc = np.ascontiguousarray(loc, np.float32)
+    des = np.ascontiguousarray(des, np.uint8)
+    return lib().orc_sift_write(os.fsencode(path), _p(loc), loc.shape[1], _p(des), len(des))
+
+
+def sift_read(path):
+    nloc = C.c_int(0)
+    n = lib().orc_sift_read(os.fsencode(path), None, None, 0, C.byref(nloc))
+    if n <= 0:
+        return None
+    loc = np.empty((n, nloc.value), np.float32)
+    des = np.empty((n, 128), np.uint8)
+    lib().orc_sift_read(os.fsencode(path), _p(loc), _p(des), n, C.byref(nloc))
+    return loc, des
+
+
+def matchtxt_record(name0, name1, matches0):
+    m = np.ascontiguousarray(matches0, np.int32)
+    buf = C.create_string_buffer(64 + 32 * max(len(m), 1))
+    ln = lib().orc_matchtxt_record(os.fsencode(name0), os.fsencode(name1), _p(m), len(m), buf, len(buf))
+    return buf.raw[:ln].decode()
+
+
+def image_pairs(n, consecutive, discrete):
+    disc = np.ascontiguousarray(discrete, np.int32)
+    cap = n * (consecutive + len(disc)) + 1
+    out = np.empty((cap, 2), np.int32)
+    c = lib().orc_image_pairs(n, consecutive, _p(disc), len(disc), _p(out), cap)
+    return out[:c]
+
+
+def mat_write_pmatch(image1, image2, fc1, fc2, idx1, idx2, reservation=0):
+    a = np.ascontiguousarray(idx1, np.int32)
+    b = np.ascontiguousarray(idx2, np.int32)
+    return lib().orc_mat_write_pmatch(os.fsencode(image1), os.fsencode(image2), fc1, fc2, len(a), _p(a), _p(b), reservation)
+
+
+def mat_get_pmatch(image, other, fc_other, cap=1 << 20):
+    a = np.empty(cap, np.int32)
+    b = np.empty(cap, np.int32)
+    nm = lib().orc_mat_get_pmatch(os.fsencode(image), os.fsencode(other), fc_other, _p(a), _p(b), cap)
+    return a[:nm], b[:nm]

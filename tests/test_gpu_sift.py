@@ -1,0 +1,134 @@
+"""GPU parity: SIFT-128 u8 matcher (HIP, through the C ABI) against the CPU oracle.
+
+Bar: bit-exact indices, distances and match lists (integer arithmetic)."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from visual_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(1, 1), (1, 5), (5, 1), (2, 2), (37, 91), (256, 256), (257, 255), (300, 700), (777, 2048), (1000, 513)]
+
+
+def _check_pair(matcher, a, b, ratio=(4, 5)):
+    s0, s1 = matcher.upload_u8(a), matcher.upload_u8(b)
+    try:
+        gi, gd1, gd2 = matcher.knn2(s0, s1)
+        oi, od1, od2 = orc.knn2_u8(a, b)
+        np.testing.assert_array_equal(gd1, od1)
+        np.testing.assert_array_equal(gi, oi)
+        np.testing.assert_array_equal(gd2, od2)
+        for mutual in (True, False):
+            fr = ratio[0] / ratio[1] if ratio else None
+            g0, g1, gd = matcher.match_pair(s0, s1, ratio=fr, mutual=mutual, return_dist=True)
+            o0, o1, od = orc.match_u8(a, b, orc.params(ratio, mutual))
+            np.testing.assert_array_equal(g0, o0)
+            np.testing.assert_array_equal(g1, o1)
+            np.testing.assert_array_equal(gd, od)
+            gm0, gm1 = matcher.match_pair_dense(s0, s1, ratio=fr, mutual=mutual)
+            om0, om1 = orc.match_dense_u8(a, b, orc.params(ratio, mutual))
+            np.testing.assert_array_equal(gm0, om0)
+            np.testing.assert_array_equal(gm1, om1)
+        return len(o0)
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)
+
+
+@pytest.mark.parametrize("n0,n1", SIZES)
+def test_pair_sizes(matcher, n0, n1):
+    a, b = synth.sift_pair(n0, n1, seed=1000 + n0 * 7 + n1)
+    _check_pair(matcher, a, b)
+
+
+def test_planted_matches_survive(matcher):
+    a, b = synth.sift_pair(777, 2048, seed=5)
+    nm = _check_pair(matcher, a, b)
+    assert nm > 100  # the planted correspondences pass ratio + mutual
+
+
+def test_no_ratio(matcher):
+    a, b = synth.sift_pair(300, 400, seed=6)
+    _check_pair(matcher, a, b, ratio=None)
+
+
+def test_ties_lowest_index(matcher):
+    """Duplicate rows on both sides: every tie must resolve to the lowest index."""
+    rng = np.random.default_rng(7)
+    base = synth.sift_like(40, rng)
+    a = np.concatenate([base, base[:17], base[5:9]])          # duplicate queries
+    b = np.concatenate([base[::-1], base[3:30], base[:40]])     # duplicate train rows
+    _check_pair(matcher, a, b)
+    _check_pair(matcher, a, b, ratio=None)
+
+
+def test_extreme_values(matcher):
+    """All-0 and all-255 rows reach the largest possible distance 128*255^2."""
+    a = np.zeros((70, 128), np.uint8)
+    b = np.full((90, 128), 255, np.uint8)
+    a[1::2] = 255
+    b[::3] = 0
+    rng = np.random.default_rng(8)
+    a[10:20] = rng.integers(0, 256, (10, 128), dtype=np.uint8)
+    b[40:60] = rng.integers(0, 256, (20, 128), dtype=np.uint8)
+    _check_pair(matcher, a, b, ratio=None)
+    _check_pair(matcher, a, b)
+
+
+def test_uniform_random_bytes(matcher):
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, 256, (513, 128), dtype=np.uint8)
+    b = rng.integers(0, 256, (700, 128), dtype=np.uint8)
+    _check_pair(matcher, a, b)
+
+
+def test_empty_sets(matcher):
+    rng = np.random.default_rng(10)
+    a = synth.sift_like(10, rng)
+    e = np.zeros((0, 128), np.uint8)
+    s0, s1, se = matcher.upload_u8(a), matcher.upload_u8(a), matcher.upload_u8(e)
+    for x, y in ((s0, se), (se, s1), (se, se)):
+        i0, i1 = matcher.match_pair(x, y)
+        assert len(i0) == 0 and len(i1) == 0
+    off, i0, i1 = matcher.match_pairs([[s0, se], [s0, s1], [se, s1]])
+    assert off[0] == 0 and off[1] == 0 and off[3] == off[2]
+    o0, o1, _ = orc.match_u8(a, a, orc.params((4, 5), True))
+    np.testing.assert_array_equal(i0, o0)
+    np.testing.assert_array_equal(i1, o1)
+    for s in (s0, s1, se):
+        matcher.release(s)
+
+
+def test_train_set_larger_than_one_chunk(matcher):
+    """More than 8192 train rows: per-chunk partial results are merged."""
+    a, b = synth.sift_pair(300, 8192 + 300, seed=11)
+    # plant exact duplicates across the chunk boundary to exercise the tie-break there
+    b[8192 + 5] = b[100]
+    b[8192 + 6] = a[7]
+    b[50] = a[7]
+    _check_pair(matcher, a, b)
+
+
+def test_batch_of_pairs(matcher):
+    rng = np.random.default_rng(12)
+    sizes = [300, 0, 777, 64, 1025]
+    imgs = []
+    base = synth.sift_like(400, rng)
+    for n in sizes:
+        x = synth.sift_like(n, rng)
+        k = min(n, 400) // 2
+        if k:
+            x[:k] = np.clip(base[:k].astype(np.int32) + rng.integers(-4, 5, (k, 128)), 0, 255).astype(np.uint8)
+        imgs.append(x)
+    ids = [matcher.upload_u8(x) for x in imgs]
+    pairs = [(i, j) for i in range(len(ids)) for j in range(len(ids)) if i != j]
+    off, i0, i1 = matcher.match_pairs([[ids[i], ids[j]] for i, j in pairs])
+    assert off[0] == 0 and off[-1] == len(i0)
+    for k, (i, j) in enumerate(pairs):
+        o0, o1, _ = orc.match_u8(imgs[i], imgs[j], orc.params((4, 5), True))
+        np.testing.assert_array_equal(i0[off[k]:off[k + 1]], o0)
+        np.testing.assert_array_equal(i1[off[k]:off[k + 1]], o1)
+    for s in ids:
+        matcher.release(s)

@@ -1,0 +1,43 @@
+"""MI355X-native descriptor matching for the VisualSfM workflow of thuanaislab/visual_slam.
+
+The compute path lives in ``libvsm.so`` (hand-written HIP for gfx950 behind a C ABI,
+``include/vsm.h``).  This package is the thin host-side mirror of the reference's Python
+interface around that path (``Others/SuperPoint_data/main.py`` helper names and argument
+meaning), bound with ctypes.  There is no CPU fallback: without the built library or
+without a gfx950 device every compute call raises.
+"""
+from ._binding import (  # noqa: F401
+    VsmError,
+    Matcher,
+    lib,
+    lib_path,
+    METRIC_DOT,
+    METRIC_L2,
+    LAYOUT_ROWS,
+    LAYOUT_DIM_MAJOR,
+    NO_SECOND,
+)
+from .host import (  # noqa: F401
+    generate_imagePairs,
+    generate_exhaustive_pairs,
+    get_list_matching_pairs,
+    save_matching_sfm,
+    save_feature_locations,
+    read_feature_locations,
+    read_sift,
+    write_sift,
+    write_pmatch,
+    get_pmatch,
+    get_match_count,
+    nearest_embed,
+    mutual_nn_match,
+)
+
+__all__ = [
+    "VsmError", "Matcher", "lib", "lib_path",
+    "METRIC_DOT", "METRIC_L2", "LAYOUT_ROWS", "LAYOUT_DIM_MAJOR", "NO_SECOND",
+    "generate_imagePairs", "generate_exhaustive_pairs", "get_list_matching_pairs",
+    "save_matching_sfm", "save_feature_locations", "read_feature_locations",
+    "read_sift", "write_sift", "write_pmatch", "get_pmatch", "get_match_count",
+    "nearest_embed", "mutual_nn_match",
+]

@@ -1,0 +1,287 @@
+"""ctypes binding of libvsm.so (C ABI: include/vsm.h)."""
+import ctypes as C
+import os
+from fractions import Fraction
+
+import numpy as np
+
+METRIC_DOT, METRIC_L2 = 0, 1
+LAYOUT_ROWS, LAYOUT_DIM_MAJOR = 0, 1
+NO_SECOND = 2**31 - 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libvsm.so")
+
+
+class VsmError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("vsm error %d: %s" % (code, message))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("ratio_num", C.c_int32),
+        ("ratio_den", C.c_int32),
+        ("mutual", C.c_int32),
+        ("reserved", C.c_int32),
+        ("max_dist_sq", C.c_int64),
+        ("min_score", C.c_float),
+        ("max_dist_sq_f", C.c_float),
+    ]
+
+
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f32p = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+
+# name -> (restype, argtypes); one entry per declaration in include/vsm.h
+SIGNATURES = {
+    "vsm_create": (C.c_void_p, [C.c_int]),
+    "vsm_destroy": (None, [C.c_void_p]),
+    "vsm_last_error": (C.c_char_p, [C.c_void_p]),
+    "vsm_synchronize": (C.c_int, [C.c_void_p]),
+    "vsm_stream": (C.c_void_p, [C.c_void_p]),
+    "vsm_upload_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "vsm_upload_u8_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "vsm_upload_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "vsm_upload_f32_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "vsm_release_set": (C.c_int, [C.c_void_p, C.c_int]),
+    "vsm_set_count": (C.c_int, [C.c_void_p, C.c_int]),
+    "vsm_match_pair": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "vsm_match_pair_dense": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_int,
+                                       C.c_void_p, C.c_void_p]),
+    "vsm_match_pairs": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Params), C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]),
+    "vsm_match_pairs_device": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Params), C.c_int]),
+    "vsm_fetch_matches": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]),
+    "vsm_knn2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsm_merge_top2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsm_nearest_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_void_p]),
+    "vsm_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "vsm_last_kernel_ms": (C.c_float, [C.c_void_p]),
+    "vsm_sift_read": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vsm_sift_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "vsm_feature_txt_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int]),
+    "vsm_feature_txt_read": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int]),
+    "vsm_matchtxt_append_dense": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int]),
+    "vsm_matchtxt_append": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "vsm_image_pairs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "vsm_image_pairs_exhaustive": (C.c_longlong, [C.c_int, C.c_void_p, C.c_longlong]),
+    "vsm_mat_write_pmatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "vsm_mat_get_pmatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "vsm_mat_get_match_count": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libvsm.so once.  Raises if it has not been built (python __graft_entry__.py)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise VsmError(-2, "%s is missing: build it with `make -C visual_slam_amd/csrc`" % path)
+        handle = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def ratio_to_fraction(ratio):
+    """Lowe ratio as an exact rational (the device test is integer-exact)."""
+    if ratio is None or ratio <= 0:
+        return 0, 1
+    fr = Fraction(float(ratio)).limit_denominator(1000)
+    return fr.numerator, fr.denominator
+
+
+def make_params(ratio=0.8, mutual=True, max_dist_sq=-1, min_score=float("-inf"), max_dist_sq_f=-1.0):
+    num, den = ratio_to_fraction(ratio)
+    return Params(num, den, 1 if mutual else 0, 0, int(max_dist_sq), float(min_score), float(max_dist_sq_f))
+
+
+class Matcher:
+    """One matching context on one GPU (single-threaded, like the reference's classes)."""
+
+    def __init__(self, device=0):
+        self._l = lib()
+        self._h = self._l.vsm_create(int(device))
+        if not self._h:
+            raise VsmError(-2, self._l.vsm_last_error(None).decode())
+        self._kinds = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.vsm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc < 0:
+            raise VsmError(rc, self._l.vsm_last_error(self._h).decode())
+        return rc
+
+    # ---- sets -----------------------------------------------------------------------
+    def upload_u8(self, des):
+        des = np.ascontiguousarray(des, dtype=np.uint8)
+        if des.ndim != 2 or des.shape[1] != 128:
+            raise ValueError("expected uint8 [n, 128]")
+        sid = self._check(self._l.vsm_upload_u8(self._h, _ptr(des), des.shape[0]))
+        self._kinds[sid] = ("u8", des.shape[0])
+        return sid
+
+    def upload_u8_device(self, dev_ptr, n):
+        sid = self._check(self._l.vsm_upload_u8_device(self._h, C.c_void_p(int(dev_ptr)), int(n)))
+        self._kinds[sid] = ("u8", int(n))
+        return sid
+
+    def upload_f32(self, des, layout=LAYOUT_ROWS):
+        des = np.ascontiguousarray(des, dtype=np.float32)
+        if des.ndim != 2:
+            raise ValueError("expected float32 2-D array")
+        n, dim = (des.shape[0], des.shape[1]) if layout == LAYOUT_ROWS else (des.shape[1], des.shape[0])
+        sid = self._check(self._l.vsm_upload_f32(self._h, _ptr(des), n, dim, layout))
+        self._kinds[sid] = ("f32", n)
+        return sid
+
+    def upload_f32_device(self, dev_ptr, n, dim, layout=LAYOUT_ROWS):
+        sid = self._check(self._l.vsm_upload_f32_device(self._h, C.c_void_p(int(dev_ptr)), int(n), int(dim), layout))
+        self._kinds[sid] = ("f32", int(n))
+        return sid
+
+    def release(self, sid):
+        self._check(self._l.vsm_release_set(self._h, sid))
+        self._kinds.pop(sid, None)
+
+    def count(self, sid):
+        return self._check(self._l.vsm_set_count(self._h, sid))
+
+    # ---- matching ---------------------------------------------------------------------
+    def match_pair(self, set0, set1, ratio=0.8, mutual=True, max_dist_sq=-1, metric=METRIC_L2,
+                   min_score=float("-inf"), max_dist_sq_f=-1.0, return_dist=False):
+        p = make_params(ratio, mutual, max_dist_sq, min_score, max_dist_sq_f)
+        kind, n0 = self._kinds[set0]
+        cap = max(n0, 1)
+        idx0 = np.empty(cap, np.int32)
+        idx1 = np.empty(cap, np.int32)
+        dist = np.empty(cap, np.int32 if kind == "u8" else np.float32) if return_dist else None
+        nm = self._check(self._l.vsm_match_pair(self._h, set0, set1, C.byref(p), metric,
+                                                _ptr(idx0), _ptr(idx1), _ptr(dist), cap))
+        if return_dist:
+            return idx0[:nm].copy(), idx1[:nm].copy(), dist[:nm].copy()
+        return idx0[:nm].copy(), idx1[:nm].copy()
+
+    def match_pair_dense(self, set0, set1, ratio=0.8, mutual=True, max_dist_sq=-1, metric=METRIC_L2,
+                         min_score=float("-inf"), max_dist_sq_f=-1.0):
+        p = make_params(ratio, mutual, max_dist_sq, min_score, max_dist_sq_f)
+        n0, n1 = self._kinds[set0][1], self._kinds[set1][1]
+        m0 = np.empty(max(n0, 1), np.int32)
+        m1 = np.empty(max(n1, 1), np.int32)
+        self._check(self._l.vsm_match_pair_dense(self._h, set0, set1, C.byref(p), metric, _ptr(m0), _ptr(m1)))
+        return m0[:n0].copy(), m1[:n1].copy()
+
+    def match_pairs(self, pairs, ratio=0.8, mutual=True, max_dist_sq=-1, cap=None):
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        p = make_params(ratio, mutual, max_dist_sq)
+        if cap is None:
+            cap = int(sum(self._kinds[int(a)][1] for a in pairs[:, 0])) or 1
+        off = np.empty(len(pairs) + 1, np.int64)
+        idx0 = np.empty(cap, np.int32)
+        idx1 = np.empty(cap, np.int32)
+        tot = self._check(self._l.vsm_match_pairs(self._h, _ptr(pairs), len(pairs), C.byref(p), METRIC_L2,
+                                                  _ptr(off), _ptr(idx0), _ptr(idx1), cap))
+        return off, idx0[:tot].copy(), idx1[:tot].copy()
+
+    def match_pairs_device(self, pairs, ratio=0.8, mutual=True, max_dist_sq=-1):
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        p = make_params(ratio, mutual, max_dist_sq)
+        return self._check(self._l.vsm_match_pairs_device(self._h, _ptr(pairs), len(pairs), C.byref(p), METRIC_L2))
+
+    def fetch_matches(self, npairs, total):
+        off = np.empty(npairs + 1, np.int64)
+        idx0 = np.empty(max(total, 1), np.int32)
+        idx1 = np.empty(max(total, 1), np.int32)
+        self._check(self._l.vsm_fetch_matches(self._h, _ptr(off), _ptr(idx0), _ptr(idx1), max(total, 1)))
+        return off, idx0[:total], idx1[:total]
+
+    def knn2(self, set_q, set_db, metric=METRIC_L2, want_idx2=False):
+        kind, nq = self._kinds[set_q]
+        dt = np.int32 if kind == "u8" else np.float32
+        idx1 = np.empty(max(nq, 1), np.int32)
+        idx2 = np.empty(max(nq, 1), np.int32) if want_idx2 else None
+        d1 = np.empty(max(nq, 1), dt)
+        d2 = np.empty(max(nq, 1), dt)
+        self._check(self._l.vsm_knn2(self._h, set_q, set_db, metric, _ptr(idx1), _ptr(idx2), _ptr(d1), _ptr(d2)))
+        if want_idx2:
+            return idx1[:nq], idx2[:nq], d1[:nq], d2[:nq]
+        return idx1[:nq], d1[:nq], d2[:nq]
+
+    def nearest_embed(self, x, emb, want_result=True):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        emb = np.ascontiguousarray(emb, dtype=np.float32)
+        b, d = x.shape[0], x.shape[1]
+        npts = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
+        argmin = np.empty((b, npts), np.int64)
+        res = np.empty((b, d, npts), np.float32) if want_result else None
+        self._check(self._l.vsm_nearest_embed(self._h, _ptr(x), b, d, npts, _ptr(emb), emb.shape[1],
+                                              _ptr(argmin), _ptr(res)))
+        return (res.reshape(x.shape) if want_result else None), argmin.reshape((b,) + tuple(x.shape[2:]))
+
+    # ---- measurement --------------------------------------------------------------------
+    def set_timing(self, on=True):
+        self._check(self._l.vsm_set_timing(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        return float(self._l.vsm_last_kernel_ms(self._h))
+
+    def synchronize(self):
+        self._check(self._l.vsm_synchronize(self._h))
+
+    def stream(self):
+        return self._l.vsm_stream(self._h)
+
+
+def merge_top2_f32(k1, k2, i1, i2, base, metric):
+    """Host merge of per-slice 2-NN lists (arrays [nslices, nq])."""
+    k1 = np.ascontiguousarray(k1, np.float32)
+    k2 = np.ascontiguousarray(k2, np.float32)
+    i1 = np.ascontiguousarray(i1, np.int32)
+    i2 = np.ascontiguousarray(i2, np.int32)
+    base = np.ascontiguousarray(base, np.int64)
+    ns, nq = k1.shape
+    ok1 = np.empty(nq, np.float32)
+    ok2 = np.empty(nq, np.float32)
+    oi1 = np.empty(nq, np.int64)
+    oi2 = np.empty(nq, np.int64)
+    rc = lib().vsm_merge_top2_f32(_ptr(k1), _ptr(k2), _ptr(i1), _ptr(i2), _ptr(base), ns, nq, metric,
+                                  _ptr(ok1), _ptr(ok2), _ptr(oi1), _ptr(oi2))
+    if rc < 0:
+        raise VsmError(rc, "vsm_merge_top2_f32")
+    return ok1, ok2, oi1, oi2

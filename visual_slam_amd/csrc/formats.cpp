@@ -1,0 +1,615 @@
+// VisualSfM interchange files: .sift feature files, the three-line-per-pair match txt, the
+// keypoint txt, and .mat putative-match records.  Host code only.
+//
+// Layouts follow the reference's readers/writers:
+//   .sift      Others/visualSfM_Sift_file/Match_modified/FeaturePoints.{h,cpp}
+//   .mat       Others/visualSfM_Sift_file/Match_modified/MatchFile.{h,cpp}
+//   match txt  Others/SuperPoint_data/main.py:114-155
+//   keypoints  Others/SuperPoint_data/main.py:133-140, FeaturePoints.cpp:326-369
+#include "../../include/vsm.h"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ---- small I/O helpers --------------------------------------------------------------
+class Fd {
+public:
+    explicit Fd(int fd = -1) : fd_(fd) {}
+    ~Fd() { if (fd_ >= 0) ::close(fd_); }
+    Fd(const Fd&) = delete;
+    Fd& operator=(const Fd&) = delete;
+    bool ok() const { return fd_ >= 0; }
+    int get() const { return fd_; }
+    bool write_all(const void* p, size_t n) const
+    {
+        const char* c = static_cast<const char*>(p);
+        while (n) {
+            ssize_t w = ::write(fd_, c, n);
+            if (w < 0 && errno == EINTR) continue;
+            if (w <= 0) return false;
+            c += w;
+            n -= (size_t)w;
+        }
+        return true;
+    }
+    // returns bytes read (short at EOF) or -1
+    ssize_t read_upto(void* p, size_t n) const
+    {
+        char* c = static_cast<char*>(p);
+        size_t got = 0;
+        while (got < n) {
+            ssize_t r = ::read(fd_, c + got, n - got);
+            if (r < 0 && errno == EINTR) continue;
+            if (r < 0) return -1;
+            if (r == 0) break;
+            got += (size_t)r;
+        }
+        return (ssize_t)got;
+    }
+    bool read_exact(void* p, size_t n) const { return read_upto(p, n) == (ssize_t)n; }
+    bool seek(off_t o) const { return ::lseek(fd_, o, SEEK_SET) >= 0; }
+private:
+    int fd_;
+};
+
+constexpr int32_t fourcc(char a, char b, char c, char d)
+{
+    return (int32_t)((uint32_t)(uint8_t)a | ((uint32_t)(uint8_t)b << 8) | ((uint32_t)(uint8_t)c << 16) |
+                     ((uint32_t)(uint8_t)d << 24));
+}
+
+// ---- .sift (FeaturePoints.h:55-90) ----------------------------------------------------
+constexpr int32_t kSiftName = fourcc('S', 'I', 'F', 'T');
+constexpr int32_t kMserName = fourcc('M', 'S', 'E', 'R');
+constexpr int32_t kSiftV4 = fourcc('V', '4', '.', '0');
+constexpr int32_t kSiftV5 = fourcc('V', '5', '.', '0');
+constexpr int32_t kSiftEof = fourcc('\xff', 'E', 'O', 'F');
+
+struct SiftHeader {
+    int32_t name, version, npoint, nloc_dim, ndes_dim;
+};
+
+// ---- decimal formatting -----------------------------------------------------------
+inline char* put_int(char* p, int v)
+{
+    char tmp[12];
+    int n = 0;
+    unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    do {
+        tmp[n++] = (char)('0' + u % 10);
+        u /= 10;
+    } while (u);
+    if (v < 0) *p++ = '-';
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+bool append_file(const char* path, const std::string& bytes)
+{
+    // main.py:143-155: append if the file exists, else create
+    Fd f(::open(path, O_CREAT | O_WRONLY | O_APPEND, 0644));
+    return f.ok() && f.write_all(bytes.data(), bytes.size());
+}
+
+}  // namespace
+
+// =====================================================================================
+// .sift
+// =====================================================================================
+extern "C" int vsm_sift_read(const char* path, float* locbuf, uint8_t* desbuf, int nmax,
+                             int* npoint, int* nloc_dim)
+{
+    if (npoint) *npoint = 0;
+    if (nloc_dim) *nloc_dim = 0;
+    if (!path) return 0;
+    Fd f(::open(path, O_RDONLY));
+    if (!f.ok()) return 0;
+    SiftHeader h;
+    if (!f.read_exact(&h, sizeof h)) return 0;
+    const bool name_ok = h.name == kSiftName || h.name == kMserName;
+    const bool ver_ok = h.version == kSiftV4 || h.version == kSiftV5;
+    // FeaturePoints.cpp:396-402: the reader accepts only 128-d descriptors
+    if (!name_ok || !ver_ok || h.npoint <= 0 || h.nloc_dim <= 0 || h.ndes_dim != VSM_DESC_DIM_U8) return 0;
+    if (npoint) *npoint = h.npoint;
+    if (nloc_dim) *nloc_dim = h.nloc_dim;
+    if (!locbuf && !desbuf) return h.npoint;
+    const int take = std::min(std::max(nmax, 0), h.npoint);
+    const size_t loc_bytes = sizeof(float) * (size_t)h.npoint * h.nloc_dim;
+    if (locbuf) {
+        // the location block is stored for all points; hand back the first `take`
+        const size_t want = sizeof(float) * (size_t)take * h.nloc_dim;
+        if (!f.read_exact(locbuf, want)) return 0;
+    }
+    if (desbuf) {
+        if (!f.seek((off_t)(sizeof h + loc_bytes))) return 0;
+        if (!f.read_exact(desbuf, (size_t)take * VSM_DESC_DIM_U8)) return 0;
+    }
+    return h.npoint;
+}
+
+extern "C" int vsm_sift_write(const char* path, const float* loc, int nloc_dim,
+                              const uint8_t* des, int npoint)
+{
+    if (!path || npoint < 0 || nloc_dim <= 0 || (npoint > 0 && (!loc || !des))) return 0;
+    // FeaturePoints.cpp:233: created owner read/write
+    Fd f(::open(path, O_CREAT | O_WRONLY | O_TRUNC, S_IRUSR | S_IWUSR));
+    if (!f.ok()) return 0;
+    const SiftHeader h = {kSiftName, kSiftV4, npoint, nloc_dim, VSM_DESC_DIM_U8};
+    const int32_t eof = kSiftEof;
+    bool ok = f.write_all(&h, sizeof h);
+    ok = ok && f.write_all(loc, sizeof(float) * (size_t)npoint * nloc_dim);
+    ok = ok && f.write_all(des, (size_t)npoint * VSM_DESC_DIM_U8);
+    ok = ok && f.write_all(&eof, sizeof eof);
+    return ok ? 1 : 0;
+}
+
+// =====================================================================================
+// keypoint txt
+// =====================================================================================
+extern "C" int vsm_feature_txt_write(const char* path, const float* xy, int m)
+{
+    if (!path || m < 0 || (m > 0 && !xy)) return VSM_EINVAL;
+    // main.py:133-140: row 0 = "m 0", then "int(x) int(y)" (truncated toward zero)
+    std::string out;
+    out.reserve(16 * ((size_t)m + 1));
+    char line[40];
+    char* p = put_int(line, m);
+    *p++ = ' '; *p++ = '0'; *p++ = '\n';
+    out.append(line, p - line);
+    for (int i = 0; i < m; ++i) {
+        p = put_int(line, (int)xy[2 * i]);
+        *p++ = ' ';
+        p = put_int(p, (int)xy[2 * i + 1]);
+        *p++ = '\n';
+        out.append(line, p - line);
+    }
+    Fd f(::open(path, O_CREAT | O_WRONLY | O_TRUNC, 0644));
+    if (!f.ok() || !f.write_all(out.data(), out.size())) return VSM_EIO;
+    return m;
+}
+
+extern "C" int vsm_feature_txt_read(const char* path, float* xy, int cap)
+{
+    if (!path) return VSM_EINVAL;
+    FILE* fp = fopen(path, "r");
+    if (!fp) return VSM_EIO;
+    int m = 0, tmp = 0;
+    if (fscanf(fp, "%d %d", &m, &tmp) != 2 || m < 0) {
+        fclose(fp);
+        return VSM_EFORMAT;
+    }
+    // FeaturePoints.cpp:336-355: x, y per row
+    int got = 0;
+    for (; got < m; ++got) {
+        float x, y;
+        if (fscanf(fp, "%f %f", &x, &y) != 2) break;
+        if (xy && got < cap) {
+            xy[2 * got] = x;
+            xy[2 * got + 1] = y;
+        }
+    }
+    fclose(fp);
+    if (got != m) return VSM_EFORMAT;
+    return m;
+}
+
+// =====================================================================================
+// match txt
+// =====================================================================================
+static int matchtxt_emit(const char* path, const char* name0, const char* name1,
+                         const int32_t* idx0, const int32_t* idx1, int nm, int n0)
+{
+    std::string rec;
+    rec.reserve(64 + (size_t)nm * 14);
+    rec.append(name0).append(" ").append(name1).append(" ");
+    char num[16];
+    rec.append(num, put_int(num, nm) - num);
+    rec.push_back('\n');
+    for (int line = 0; line < 2; ++line) {
+        const int32_t* v = line ? idx1 : idx0;
+        for (int k = 0; k < nm; ++k) {
+            rec.append(num, put_int(num, v[k]) - num);
+            // main.py:124-129: no separator after the entry of the last keypoint
+            if (idx0[k] != n0 - 1) rec.push_back(' ');
+        }
+        rec.push_back('\n');
+    }
+    return append_file(path, rec) ? nm : VSM_EIO;
+}
+
+extern "C" int vsm_matchtxt_append(const char* path, const char* name0, const char* name1,
+                                   const int32_t* idx0, const int32_t* idx1, int nm, int n0)
+{
+    if (!path || !name0 || !name1 || nm < 0 || (nm > 0 && (!idx0 || !idx1))) return VSM_EINVAL;
+    return matchtxt_emit(path, name0, name1, idx0, idx1, nm, n0);
+}
+
+extern "C" int vsm_matchtxt_append_dense(const char* path, const char* name0, const char* name1,
+                                         const int32_t* matches0, int n)
+{
+    if (!path || !name0 || !name1 || n < 0 || (n > 0 && !matches0)) return VSM_EINVAL;
+    std::vector<int32_t> i0, i1;
+    for (int i = 0; i < n; ++i)
+        if (matches0[i] != -1) {
+            i0.push_back(i);
+            i1.push_back(matches0[i]);
+        }
+    return matchtxt_emit(path, name0, name1, i0.data(), i1.data(), (int)i0.size(), n);
+}
+
+// =====================================================================================
+// pair lists
+// =====================================================================================
+extern "C" int vsm_image_pairs(int nimages, int consecutive, const int32_t* discrete, int ndiscrete,
+                               int32_t* pairs, int cap)
+{
+    if (nimages < 0 || consecutive < 0 || ndiscrete < 0 || (ndiscrete > 0 && !discrete)) return VSM_EINVAL;
+    int count = 0;
+    auto emit = [&](int a, int b) {
+        if (pairs && count < cap) {
+            pairs[2 * count] = a;
+            pairs[2 * count + 1] = b;
+        }
+        ++count;
+    };
+    for (int i = 0; i < nimages; ++i) {
+        for (int step = 1; step <= consecutive; ++step)
+            if (i + step < nimages) emit(i, i + step);
+        for (int d = 0; d < ndiscrete; ++d)
+            if (i + discrete[d] < nimages) emit(i, i + discrete[d]);
+    }
+    return count;
+}
+
+extern "C" long long vsm_image_pairs_exhaustive(int nimages, int32_t* pairs, long long cap)
+{
+    if (nimages < 0) return VSM_EINVAL;
+    long long count = 0;
+    for (int i = 0; i < nimages; ++i)
+        for (int j = i + 1; j < nimages; ++j) {
+            if (pairs && count < cap) {
+                pairs[2 * count] = i;
+                pairs[2 * count + 1] = j;
+            }
+            ++count;
+        }
+    return count;
+}
+
+// =====================================================================================
+// .mat
+// =====================================================================================
+namespace {
+
+constexpr int32_t kMatVersion = fourcc('M', 'T', '0', '3');
+constexpr int32_t kRecVersion = fourcc('M', 'R', 'V', '3');
+constexpr int kMaxPath = 260;  // MAX_PATH of the reference build
+
+struct MatHeader {  // MatchFile.h:189-196
+    int32_t version, file_count, definition_size, definition_buf, feature_count;
+};
+struct MatRecLoc {  // MatchFile.h:198-206 (file_name continues for extra_size bytes)
+    int32_t fcount, read_loc, block_size, trash_size, extra_size;
+    char file_name[4];
+};
+struct MatGeometry {  // TwoViewGeometry, MatchFile.h:68-83
+    int32_t NF, NE, NH, NH2;
+    float F[3][3], R[3][3], T[3], F1, F2, H[3][3], GE, AA;
+};
+struct MatRecord {  // MatchRecordV3, MatchFile.h:174-184
+    int32_t version;
+    MatGeometry tvg;
+    int32_t extra[7];
+};
+static_assert(sizeof(MatHeader) == 20 && sizeof(MatRecLoc) == 24, "on-disk sizes");
+static_assert(sizeof(MatGeometry) == 152 && sizeof(MatRecord) == 184, "on-disk sizes");
+
+// MatchFile.cpp:372-406 (POSIX separators)
+std::string relative_name(const std::string& self, const std::string& other)
+{
+    size_t i = 0;
+    while (i < self.size() && i < other.size() && self[i] == other[i]) ++i;
+    while (i > 0 && (i >= self.size() || self[i] != '/')) --i;
+    if (i == 0) return other;
+    std::string rel;
+    int up_self = 0, down_other = 0;
+    for (size_t p = i + 1; p < self.size(); ++p)
+        if (self[p] == '/' && (p + 1 >= self.size() || self[p + 1] != '/')) {
+            rel += "../";
+            ++up_self;
+        }
+    for (size_t p = i + 1; p < other.size(); ++p)
+        if (other[p] == '/' && (p + 1 >= other.size() || other[p + 1] != '/')) ++down_other;
+    if (up_self <= 1 || down_other <= 1) return rel + other.substr(i + 1);
+    return other;
+}
+
+// One image's match database, directory held in memory.
+class MatFile {
+public:
+    bool open(const std::string& image, bool for_write)
+    {
+        image_ = image;
+        const std::string path = image + ".mat";
+        fd_ = ::open(path.c_str(), for_write ? (O_CREAT | O_RDWR) : O_RDONLY, S_IRUSR | S_IWUSR);
+        if (fd_ < 0) return false;
+        MatHeader h;
+        ssize_t got = read_at(0, &h, sizeof h);
+        if (got == (ssize_t)sizeof h && h.definition_size > 0 && h.definition_buf >= h.definition_size &&
+            h.version == kMatVersion && h.file_count >= 0) {
+            hdr_ = h;
+            dir_.assign((size_t)h.definition_buf, 0);
+            if (read_at(sizeof h, dir_.data(), (size_t)h.definition_size) != h.definition_size) return false;
+            index_directory();
+        } else {
+            hdr_ = MatHeader{kMatVersion, 0, 0, 0, 0};  // MatchFile.cpp:563-573
+            dir_.clear();
+            recs_.clear();
+        }
+        return true;
+    }
+    ~MatFile() { if (fd_ >= 0) ::close(fd_); }
+
+    int find(const std::string& rel) const
+    {
+        for (size_t i = 0; i < recs_.size(); ++i)
+            if (rel == rec(i)->file_name) return (int)i;
+        return -1;
+    }
+    const MatRecLoc* rec(size_t i) const { return reinterpret_cast<const MatRecLoc*>(dir_.data() + recs_[i]); }
+    MatRecLoc* rec(size_t i) { return reinterpret_cast<MatRecLoc*>(dir_.data() + recs_[i]); }
+    size_t count() const { return recs_.size(); }
+    const std::string& image() const { return image_; }
+
+    // MatchFile.cpp:455-561.  Returns the new record's index or -1.
+    int add(const std::string& rel, int reservation)
+    {
+        const int slen = ((int)rel.size() / 4 + 1) * 4;
+        const int elen = slen - 4;
+        const int rlen = elen + (int)sizeof(MatRecLoc);
+        if (hdr_.file_count == 0) {
+            hdr_.version = kMatVersion;
+            hdr_.definition_buf = std::max(20, reservation) * (kMaxPath + (int)sizeof(MatRecLoc));
+            dir_.assign((size_t)hdr_.definition_buf, 0);
+            hdr_.definition_size = 0;
+            recs_.clear();
+            append_record(rel, elen, rlen, (int32_t)sizeof(MatHeader) + hdr_.definition_buf);
+            return 0;
+        }
+        if (hdr_.definition_size + rlen < hdr_.definition_buf) {
+            const MatRecLoc* last = rec(recs_.size() - 1);
+            append_record(rel, elen, rlen, last->read_loc + last->block_size);
+            return (int)recs_.size() - 1;
+        }
+        return grow_and_add(rel, elen, rlen) ? (int)recs_.size() - 1 : -1;
+    }
+
+    bool flush_directory() const
+    {
+        return write_at(0, &hdr_, sizeof hdr_) && write_at(sizeof hdr_, dir_.data(), (size_t)hdr_.definition_size);
+    }
+    ssize_t read_at(off_t off, void* p, size_t n) const
+    {
+        if (::lseek(fd_, off, SEEK_SET) < 0) return -1;
+        char* c = static_cast<char*>(p);
+        size_t got = 0;
+        while (got < n) {
+            ssize_t r = ::read(fd_, c + got, n - got);
+            if (r < 0 && errno == EINTR) continue;
+            if (r < 0) return -1;
+            if (r == 0) break;
+            got += (size_t)r;
+        }
+        return (ssize_t)got;
+    }
+    bool write_at(off_t off, const void* p, size_t n) const
+    {
+        if (::lseek(fd_, off, SEEK_SET) < 0) return false;
+        const char* c = static_cast<const char*>(p);
+        while (n) {
+            ssize_t w = ::write(fd_, c, n);
+            if (w < 0 && errno == EINTR) continue;
+            if (w <= 0) return false;
+            c += w;
+            n -= (size_t)w;
+        }
+        return true;
+    }
+    // moves record i behind the last one (MatchFile.cpp:422-453); data is re-written by the caller
+    void move_to_end(int i)
+    {
+        if (i < 0 || i >= (int)recs_.size() - 1) return;
+        const size_t a = recs_[i], b = recs_[i + 1], len = b - a;
+        std::vector<char> tmp(dir_.begin() + a, dir_.begin() + b);
+        dir_.erase(dir_.begin() + a, dir_.begin() + b);
+        dir_.insert(dir_.begin() + (hdr_.definition_size - len), tmp.begin(), tmp.end());
+        index_directory();
+        MatRecLoc* last = rec(recs_.size() - 1);
+        const MatRecLoc* prev = rec(recs_.size() - 2);
+        last->read_loc = prev->read_loc + prev->block_size;
+    }
+
+private:
+    void index_directory()
+    {
+        // MatchFile.cpp:275-299: stop at the first implausible record
+        recs_.clear();
+        size_t p = 0;
+        for (int i = 0; i < hdr_.file_count; ++i) {
+            if (p + sizeof(MatRecLoc) > dir_.size()) break;
+            const MatRecLoc* r = reinterpret_cast<const MatRecLoc*>(dir_.data() + p);
+            if (r->read_loc <= 0 || r->block_size == 0 || r->extra_size > kMaxPath || r->extra_size < 0 ||
+                r->fcount > 1000000 || r->fcount < 0)
+                break;
+            recs_.push_back(p);
+            p += sizeof(MatRecLoc) + (size_t)r->extra_size;
+        }
+        if ((int)recs_.size() != hdr_.file_count) {
+            hdr_.file_count = (int)recs_.size();
+            hdr_.definition_size = (int32_t)p;
+        }
+    }
+    void append_record(const std::string& rel, int elen, int rlen, int32_t read_loc)
+    {
+        const size_t at = (size_t)hdr_.definition_size;
+        MatRecLoc* r = reinterpret_cast<MatRecLoc*>(dir_.data() + at);
+        memset(r, 0, (size_t)rlen);
+        r->read_loc = read_loc;
+        r->extra_size = elen;
+        memcpy(r->file_name, rel.c_str(), rel.size() + 1);
+        recs_.push_back(at);
+        hdr_.definition_size += rlen;
+        hdr_.file_count = (int)recs_.size();
+    }
+    // The directory is full: double it, relocating the data blocks that sit where the
+    // larger directory will be to the end of the file, and rotating their records to the
+    // end of the directory so that the last record stays the last block (MatchFile.cpp:494-560).
+    bool grow_and_add(const std::string& rel, int elen, int rlen)
+    {
+        const int extra_needed = rlen + hdr_.definition_buf;
+        int moved = 0, space = 0;
+        while (space < extra_needed && moved < (int)recs_.size()) {
+            space += rec(moved)->block_size + rec(moved)->trash_size;
+            ++moved;
+        }
+        if (space < extra_needed) return false;
+        std::vector<char> data((size_t)space);
+        const int32_t first_loc = rec(0)->read_loc;
+        if (read_at(first_loc, data.data(), (size_t)space) < 0) return false;
+        const MatRecLoc* last = rec(recs_.size() - 1);
+        int32_t wloc = last->read_loc + last->block_size;
+        size_t doff = 0;
+        for (int i = 0; i < moved; ++i) {
+            MatRecLoc* r = rec(i);
+            if (!write_at(wloc, data.data() + doff, (size_t)r->block_size)) return false;
+            doff += (size_t)r->block_size + (size_t)r->trash_size;
+            r->read_loc = wloc;
+            wloc += r->block_size;
+            r->trash_size = 0;
+        }
+        if (moved < (int)recs_.size()) {
+            const size_t cut = recs_[moved];
+            std::rotate(dir_.begin(), dir_.begin() + cut, dir_.begin() + hdr_.definition_size);
+        }
+        hdr_.definition_buf = hdr_.definition_buf * 2 + rlen;
+        dir_.resize((size_t)hdr_.definition_buf, 0);
+        index_directory();
+        append_record(rel, elen, rlen, wloc);
+        return true;
+    }
+
+    int fd_ = -1;
+    std::string image_;
+    MatHeader hdr_{};
+    std::vector<char> dir_;
+    std::vector<size_t> recs_;  // byte offsets of the records inside dir_
+};
+
+int mat_write_one(const std::string& image, const std::string& other, int fc_other, int nm,
+                  const int32_t* row_this, const int32_t* row_other, int reservation)
+{
+    MatFile mf;
+    if (!mf.open(image, true)) return VSM_EIO;
+    const std::string rel = relative_name(image, other);
+    if ((int)rel.size() >= kMaxPath) return VSM_EINVAL;
+    int idx = mf.find(rel);
+    if (idx < 0) idx = mf.add(rel, reservation);
+    if (idx < 0) return VSM_EIO;
+    MatRecLoc* loc = mf.rec(idx);
+    // MatchFile.cpp:781-805
+    const int fresh_size = (int)sizeof(MatRecord) + std::max(nm, 8) * (int)sizeof(int32_t) * 6;
+    if (loc->block_size == 0 || idx == (int)mf.count() - 1) {
+        loc->block_size = fresh_size;
+    } else {
+        const int need = (int)sizeof(MatRecord) + std::max(nm, 0) * (int)sizeof(int32_t) * 4;
+        if (need > loc->block_size) {
+            if (need > loc->block_size + loc->trash_size) {
+                // the old block becomes unused space in front of its successor
+                if (idx > 0) mf.rec(idx - 1)->trash_size += loc->block_size + loc->trash_size;
+                mf.move_to_end(idx);
+                idx = (int)mf.count() - 1;
+                loc = mf.rec(idx);
+                loc->block_size = fresh_size;
+                loc->trash_size = 0;
+            } else {
+                loc->block_size += loc->trash_size;
+                loc->trash_size = 0;
+            }
+        }
+    }
+    loc->fcount = fc_other;
+    if (!mf.flush_directory()) return VSM_EIO;
+    // MatchFile.cpp:813-831
+    MatRecord rec;
+    memset(&rec, 0, sizeof rec);
+    rec.version = kRecVersion;
+    rec.tvg.GE = 100.0f;
+    std::vector<char> blk(sizeof(int32_t) + sizeof rec + (size_t)std::max(nm, 0) * 8);
+    const int32_t nm32 = nm;
+    memcpy(blk.data(), &nm32, 4);
+    memcpy(blk.data() + 4, &rec, sizeof rec);
+    if (nm > 0) {
+        memcpy(blk.data() + 4 + sizeof rec, row_this, (size_t)nm * 4);
+        memcpy(blk.data() + 4 + sizeof rec + (size_t)nm * 4, row_other, (size_t)nm * 4);
+    }
+    return mf.write_at(loc->read_loc, blk.data(), blk.size()) ? VSM_OK : VSM_EIO;
+}
+
+}  // namespace
+
+extern "C" int vsm_mat_write_pmatch(const char* image1, const char* image2, int fc1, int fc2,
+                                    int nm, const int32_t* idx1, const int32_t* idx2, int reservation)
+{
+    if (!image1 || !image2 || !image1[0] || !image2[0] || nm < 0 || (nm > 0 && (!idx1 || !idx2))) return VSM_EINVAL;
+    if (strlen(image1) + 5 > (size_t)kMaxPath || strlen(image2) + 5 > (size_t)kMaxPath) return VSM_EINVAL;
+    int rc = mat_write_one(image1, image2, fc2, nm, idx1, idx2, reservation);
+    if (rc != VSM_OK) return rc;
+    return mat_write_one(image2, image1, fc1, nm, idx2, idx1, reservation);
+}
+
+extern "C" int vsm_mat_get_pmatch(const char* image, const char* other, int fc_other,
+                                  int32_t* idx_this, int32_t* idx_other, int cap)
+{
+    if (!image || !other) return 0;
+    MatFile mf;
+    if (!mf.open(image, false)) return 0;
+    const int idx = mf.find(relative_name(image, other));
+    if (idx < 0) return 0;
+    const MatRecLoc* loc = mf.rec(idx);
+    if (loc->fcount != fc_other) return 0;  // MatchFile.cpp:871
+    int32_t nm = 0;
+    if (mf.read_at(loc->read_loc, &nm, 4) != 4) return 0;
+    if (!(nm > 0 && nm <= fc_other)) return 0;  // :877
+    const int take = std::min(nm, std::max(cap, 0));
+    const off_t rows = (off_t)loc->read_loc + 4 + (off_t)sizeof(MatRecord);
+    if (idx_this && mf.read_at(rows, idx_this, (size_t)take * 4) != (ssize_t)take * 4) return 0;
+    if (idx_other && mf.read_at(rows + (off_t)nm * 4, idx_other, (size_t)take * 4) != (ssize_t)take * 4) return 0;
+    return nm;
+}
+
+extern "C" int vsm_mat_get_match_count(const char* image, const char* other, int* nm, int* nf)
+{
+    if (nm) *nm = 0;
+    if (nf) *nf = 0;
+    if (!image || !other) return 0;
+    MatFile mf;
+    if (!mf.open(image, false)) return 0;
+    const int idx = mf.find(relative_name(image, other));
+    if (idx < 0) return 0;
+    int32_t counts[3];  // NM, record version, NF (MatchFile.cpp:950-954)
+    if (mf.read_at(mf.rec(idx)->read_loc, counts, sizeof counts) != (ssize_t)sizeof counts) return 0;
+    if (nm) *nm = counts[0];
+    if (nf) *nf = counts[2];
+    return 1;
+}

@@ -1,0 +1,870 @@
+// C-ABI layer: contexts, descriptor sets, submission of pair batches, result hand-back.
+// Declarations and the reference code each entry point stands in for: include/vsm.h.
+#include "../../include/vsm.h"
+#include "vsm_internal.h"
+#include "f32_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace vsm;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8;  // a little slack so near-equal batches reuse it
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+        }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct HostBuf {  // pinned
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+enum SetKind { SET_FREE = 0, SET_U8 = 1, SET_F32 = 2 };
+
+struct DescSet {
+    SetKind kind = SET_FREE;
+    int n = 0, n_pad = 0, dim = 0;
+    void* frag = nullptr;  // u8: fragment-major int8; f32: fragment-major float
+    void* nrm = nullptr;   // u8: int32 nrm8; f32: float squared norms
+};
+
+}  // namespace
+
+struct vsm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<DescSet> sets;
+    // workspace (grow-only)
+    DevBuf d_pairs, d_items, d_rr1, d_rrj, d_rr2, d_colpart;
+    DevBuf d_slot0, d_slot1, d_slotd, d_counts, d_offsets, d_tight0, d_tight1;
+    DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage;
+    HostBuf h_pairs, h_items, h_small;
+    // last device-resident result
+    int last_npairs = 0;
+    long long last_total = 0;
+    // timing
+    int timing = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+};
+
+namespace {
+
+int fail(vsm_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((c), e_ == hipErrorOutOfMemory ? VSM_ENOMEM : VSM_ENODEV,           \
+                        "%s failed: %s", #call, hipGetErrorString(e_));                     \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int new_set_slot(vsm_ctx* c)
+{
+    for (size_t i = 0; i < c->sets.size(); ++i)
+        if (c->sets[i].kind == SET_FREE) return (int)i;
+    c->sets.emplace_back();
+    return (int)c->sets.size() - 1;
+}
+
+const DescSet* get_set(const vsm_ctx* c, int id)
+{
+    if (!c || id < 0 || id >= (int)c->sets.size() || c->sets[id].kind == SET_FREE) return nullptr;
+    return &c->sets[id];
+}
+
+int check_params(vsm_ctx* c, const vsm_params* p)
+{
+    if (!p) return fail(c, VSM_EINVAL, "params is NULL");
+    if (p->ratio_num > 0 && (p->ratio_den <= 0 || p->ratio_num > 16384 || p->ratio_den > 16384))
+        return fail(c, VSM_EINVAL, "ratio %d/%d out of range (0 < num, den <= 16384)", p->ratio_num, p->ratio_den);
+    return VSM_OK;
+}
+
+// One submission must fit this much scratch for the per-strip train-side partial minima.
+constexpr size_t kColpartBudget = (size_t)12 << 30;
+
+struct Plan {
+    std::vector<SiftPair> pairs;
+    std::vector<SiftItem> items;
+    size_t rows = 0, cols = 0, out0 = 0, out1 = 0;
+};
+
+int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
+{
+    pl.pairs.resize(npairs);
+    pl.items.clear();
+    for (int p = 0; p < npairs; ++p) {
+        const DescSet* A = get_set(c, pairs[2 * p]);
+        const DescSet* B = get_set(c, pairs[2 * p + 1]);
+        if (!A || !B) return fail(c, VSM_EINVAL, "pair %d names an unknown set", p);
+        if (A->kind != SET_U8 || B->kind != SET_U8) return fail(c, VSM_EINVAL, "pair %d mixes set kinds", p);
+        SiftPair& sp = pl.pairs[p];
+        sp.fragA = static_cast<const int8_t*>(A->frag);
+        sp.nrmA = static_cast<const int32_t*>(A->nrm);
+        sp.fragB = static_cast<const int8_t*>(B->frag);
+        sp.nrmB = static_cast<const int32_t*>(B->nrm);
+        sp.nA = A->n; sp.nB = B->n; sp.nA_pad = A->n_pad; sp.nB_pad = B->n_pad;
+        const bool empty = A->n == 0 || B->n == 0;
+        sp.nstrips = empty ? 0 : A->n_pad / kStripRows;
+        sp.nchunks = empty ? 0 : (B->n_pad + kChunkCols - 1) / kChunkCols;
+        sp.row_off = (int64_t)pl.rows;
+        sp.col_off = (int64_t)pl.cols;
+        sp.out0_off = (int64_t)pl.out0;
+        sp.out1_off = (int64_t)pl.out1;
+        pl.rows += (size_t)sp.nchunks * sp.nA_pad;
+        pl.cols += (size_t)sp.nstrips * sp.nB_pad;
+        pl.out0 += (size_t)sp.nA;
+        pl.out1 += (size_t)sp.nB;
+        for (int s = 0; s < sp.nstrips; ++s)
+            for (int ch = 0; ch < sp.nchunks; ++ch) pl.items.push_back(SiftItem{p, (int16_t)s, (int16_t)ch});
+    }
+    if (pl.cols * 4 > kColpartBudget)
+        return fail(c, VSM_EINVAL, "submission needs %zu bytes of scratch (limit %zu); submit fewer pairs per call",
+                    pl.cols * 4, kColpartBudget);
+    return VSM_OK;
+}
+
+struct RunOpts {
+    bool want_dense = false, want_knn = false, want_dist = false, want_pack = true;
+};
+
+// Queues the whole u8 pipeline for one planned submission.
+int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
+{
+    const int npairs = (int)pl.pairs.size();
+    const int nitems = (int)pl.items.size();
+    HIPCHK(c, c->h_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
+    HIPCHK(c, c->h_items.ensure(sizeof(SiftItem) * std::max(nitems, 1)));
+    HIPCHK(c, c->d_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
+    HIPCHK(c, c->d_items.ensure(sizeof(SiftItem) * std::max(nitems, 1)));
+    const size_t rows = std::max<size_t>(pl.rows, 1), cols = std::max<size_t>(pl.cols, 1);
+    const size_t out0 = std::max<size_t>(pl.out0, 1), out1 = std::max<size_t>(pl.out1, 1);
+    HIPCHK(c, c->d_rr1.ensure(rows * 4));
+    HIPCHK(c, c->d_rrj.ensure(rows * 4));
+    HIPCHK(c, c->d_rr2.ensure(rows * 4));
+    HIPCHK(c, c->d_colpart.ensure(cols * 4));
+    HIPCHK(c, c->d_slot0.ensure(out0 * 4));
+    HIPCHK(c, c->d_slot1.ensure(out0 * 4));
+    if (o.want_dist) HIPCHK(c, c->d_slotd.ensure(out0 * 4));
+    HIPCHK(c, c->d_counts.ensure(sizeof(int32_t) * std::max(npairs, 1)));
+    HIPCHK(c, c->d_offsets.ensure(sizeof(int64_t) * (npairs + 1)));
+    if (o.want_pack) {
+        HIPCHK(c, c->d_tight0.ensure(out0 * 4));
+        HIPCHK(c, c->d_tight1.ensure(out0 * 4));
+    }
+    if (o.want_dense) {
+        HIPCHK(c, c->d_dense0.ensure(out0 * 4));
+        HIPCHK(c, c->d_dense1.ensure(out1 * 4));
+    }
+    if (o.want_knn) {
+        HIPCHK(c, c->d_knnj.ensure(out0 * 4));
+        HIPCHK(c, c->d_knn1.ensure(out0 * 4));
+        HIPCHK(c, c->d_knn2.ensure(out0 * 4));
+    }
+    // the pinned staging buffers may still feed a previous copy
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (npairs) memcpy(c->h_pairs.p, pl.pairs.data(), sizeof(SiftPair) * npairs);
+    if (nitems) memcpy(c->h_items.p, pl.items.data(), sizeof(SiftItem) * nitems);
+    if (npairs) HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->h_pairs.p, sizeof(SiftPair) * npairs, hipMemcpyHostToDevice, c->stream));
+    if (nitems) HIPCHK(c, hipMemcpyAsync(c->d_items.p, c->h_items.p, sizeof(SiftItem) * nitems, hipMemcpyHostToDevice, c->stream));
+
+    c->ev_valid = false;
+    if (nitems) {
+        if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        launch_sift_knn(c->d_pairs.as<SiftPair>(), c->d_items.as<SiftItem>(), nitems,
+                        c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(),
+                        c->d_colpart.as<int32_t>(), c->stream);
+        if (c->timing) {
+            HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+            c->ev_valid = true;
+        }
+    }
+    if (npairs) {
+        SiftOutputs out{};
+        out.slot_i0 = c->d_slot0.as<int32_t>();
+        out.slot_i1 = c->d_slot1.as<int32_t>();
+        out.slot_d = o.want_dist ? c->d_slotd.as<int32_t>() : nullptr;
+        out.counts = c->d_counts.as<int32_t>();
+        if (o.want_dense) {
+            out.dense0 = c->d_dense0.as<int32_t>();
+            out.dense1 = c->d_dense1.as<int32_t>();
+        }
+        if (o.want_knn) {
+            out.knn_j1 = c->d_knnj.as<int32_t>();
+            out.knn_d1 = c->d_knn1.as<int32_t>();
+            out.knn_d2 = c->d_knn2.as<int32_t>();
+        }
+        launch_sift_finalize(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(),
+                             c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(),
+                             c->d_colpart.as<int32_t>(), rule, out, c->stream);
+        if (o.want_pack)
+            launch_pack(c->d_pairs.as<SiftPair>(), npairs, c->d_counts.as<int32_t>(),
+                        c->d_offsets.as<int64_t>(), c->d_slot0.as<int32_t>(), c->d_slot1.as<int32_t>(),
+                        c->d_tight0.as<int32_t>(), c->d_tight1.as<int32_t>(), c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    return VSM_OK;
+}
+
+MatchRule make_rule(const vsm_params* p)
+{
+    MatchRule r;
+    r.num2 = p->ratio_num > 0 ? (int64_t)p->ratio_num * p->ratio_num : 0;
+    r.den2 = (int64_t)p->ratio_den * p->ratio_den;
+    r.max_dist = p->max_dist_sq;
+    r.mutual = p->mutual ? 1 : 0;
+    return r;
+}
+
+int set_kind_of_pair(vsm_ctx* c, int set0, int set1, SetKind* kind)
+{
+    const DescSet* A = get_set(c, set0);
+    const DescSet* B = get_set(c, set1);
+    if (!A || !B) return fail(c, VSM_EINVAL, "unknown set id (%d, %d)", set0, set1);
+    if (A->kind != B->kind) return fail(c, VSM_EINVAL, "sets %d and %d hold different descriptor kinds", set0, set1);
+    if (A->kind == SET_F32 && A->dim != B->dim) return fail(c, VSM_EINVAL, "sets %d and %d differ in dimension", set0, set1);
+    *kind = A->kind;
+    return VSM_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------
+extern "C" vsm_ctx* vsm_create(int device)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        fail(nullptr, VSM_ENODEV, "no HIP device available (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        fail(nullptr, VSM_EINVAL, "device %d out of range (0..%d)", device, ndev - 1);
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        fail(nullptr, VSM_ENODEV, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        fail(nullptr, VSM_ENODEV, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fail(nullptr, VSM_ENODEV, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return nullptr;
+    }
+    vsm_ctx* c = new vsm_ctx();
+    c->device = device;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        fail(nullptr, VSM_ENODEV, "stream/event creation: %s", hipGetErrorString(e));
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void vsm_destroy(vsm_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& s : c->sets) {
+        if (s.frag) (void)hipFree(s.frag);
+        if (s.nrm) (void)hipFree(s.nrm);
+    }
+    DevBuf* bufs[] = {&c->d_pairs, &c->d_items, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart,
+                      &c->d_slot0, &c->d_slot1, &c->d_slotd, &c->d_counts, &c->d_offsets,
+                      &c->d_tight0, &c->d_tight1, &c->d_dense0, &c->d_dense1,
+                      &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage};
+    for (DevBuf* b : bufs) b->release();
+    c->h_pairs.release();
+    c->h_items.release();
+    c->h_small.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* vsm_last_error(const vsm_ctx* c)
+{
+    return c ? c->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" int vsm_synchronize(vsm_ctx* c)
+{
+    if (!c) return VSM_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VSM_OK;
+}
+
+extern "C" void* vsm_stream(vsm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int vsm_set_timing(vsm_ctx* c, int on)
+{
+    if (!c) return VSM_EINVAL;
+    c->timing = on ? 1 : 0;
+    return VSM_OK;
+}
+
+extern "C" float vsm_last_kernel_ms(vsm_ctx* c)
+{
+    if (!c || !c->ev_valid) return -1.0f;
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+// ---------------------------------------------------------------------------------
+// descriptor sets
+// ---------------------------------------------------------------------------------
+static int upload_u8_common(vsm_ctx* c, const void* src, int n, bool src_on_device)
+{
+    if (!c) return VSM_EINVAL;
+    if (n < 0 || (n > 0 && !src)) return fail(c, VSM_EINVAL, "bad descriptor buffer (n=%d)", n);
+    HIPCHK(c, hipSetDevice(c->device));
+    DescSet s;
+    s.kind = SET_U8;
+    s.n = n;
+    s.n_pad = round_up(n, kRowPad);
+    s.dim = kDescDim;
+    if (s.n_pad > 0) {
+        HIPCHK(c, hipMalloc(&s.frag, (size_t)s.n_pad * kDescDim));
+        hipError_t e = hipMalloc(&s.nrm, (size_t)s.n_pad * sizeof(int32_t));
+        if (e != hipSuccess) {
+            (void)hipFree(s.frag);
+            return fail(c, VSM_ENOMEM, "hipMalloc(norms): %s", hipGetErrorString(e));
+        }
+        const uint8_t* dsrc = static_cast<const uint8_t*>(src);
+        if (!src_on_device) {
+            e = c->d_stage.ensure((size_t)n * kDescDim);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(c->d_stage.p, src, (size_t)n * kDescDim, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) {
+                (void)hipFree(s.frag);
+                (void)hipFree(s.nrm);
+                return fail(c, VSM_ENODEV, "staging copy: %s", hipGetErrorString(e));
+            }
+            dsrc = c->d_stage.as<uint8_t>();
+        }
+        launch_sift_transform(dsrc, n, s.n_pad, static_cast<int8_t*>(s.frag), static_cast<int32_t*>(s.nrm), c->stream);
+        // the staging buffer (or the caller's host buffer) may be reused right after return
+        e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(s.frag);
+            (void)hipFree(s.nrm);
+            return fail(c, VSM_ENODEV, "descriptor transform: %s", hipGetErrorString(e));
+        }
+    }
+    const int id = new_set_slot(c);
+    c->sets[id] = s;
+    return id;
+}
+
+extern "C" int vsm_upload_u8(vsm_ctx* c, const uint8_t* des, int n) { return upload_u8_common(c, des, n, false); }
+extern "C" int vsm_upload_u8_device(vsm_ctx* c, const void* des_dev, int n) { return upload_u8_common(c, des_dev, n, true); }
+
+static int upload_f32_common(vsm_ctx* c, const void* src, int n, int dim, int layout, bool src_on_device)
+{
+    if (!c) return VSM_EINVAL;
+    if (n < 0 || (n > 0 && !src)) return fail(c, VSM_EINVAL, "bad descriptor buffer (n=%d)", n);
+    if (dim <= 0 || dim > 256) return fail(c, VSM_EINVAL, "dim %d must be in 1..256", dim);
+    if (layout != VSM_LAYOUT_ROWS && layout != VSM_LAYOUT_DIM_MAJOR) return fail(c, VSM_EINVAL, "unknown layout %d", layout);
+    HIPCHK(c, hipSetDevice(c->device));
+    DescSet s;
+    s.kind = SET_F32;
+    s.n = n;
+    s.n_pad = round_up(n, kF32RowPad);
+    s.dim = dim;
+    if (s.n_pad > 0) {
+        HIPCHK(c, hipMalloc(&s.frag, (size_t)s.n_pad * f32_dimp(dim) * sizeof(float)));
+        hipError_t e = hipMalloc(&s.nrm, ((size_t)s.n_pad + 64) * sizeof(float));
+        if (e != hipSuccess) {
+            (void)hipFree(s.frag);
+            return fail(c, VSM_ENOMEM, "hipMalloc(norms): %s", hipGetErrorString(e));
+        }
+        const float* dsrc = static_cast<const float*>(src);
+        if (!src_on_device) {
+            e = c->d_stage.ensure((size_t)n * dim * sizeof(float));
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(c->d_stage.p, src, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) {
+                (void)hipFree(s.frag);
+                (void)hipFree(s.nrm);
+                return fail(c, VSM_ENODEV, "staging copy: %s", hipGetErrorString(e));
+            }
+            dsrc = c->d_stage.as<float>();
+        }
+        launch_f32_transform(dsrc, n, s.n_pad, dim, layout == VSM_LAYOUT_DIM_MAJOR,
+                             static_cast<float*>(s.frag), static_cast<float*>(s.nrm), c->stream);
+        e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(s.frag);
+            (void)hipFree(s.nrm);
+            return fail(c, VSM_ENODEV, "descriptor transform: %s", hipGetErrorString(e));
+        }
+    }
+    const int id = new_set_slot(c);
+    c->sets[id] = s;
+    return id;
+}
+
+extern "C" int vsm_upload_f32(vsm_ctx* c, const float* des, int n, int dim, int layout)
+{
+    return upload_f32_common(c, des, n, dim, layout, false);
+}
+extern "C" int vsm_upload_f32_device(vsm_ctx* c, const void* des_dev, int n, int dim, int layout)
+{
+    return upload_f32_common(c, des_dev, n, dim, layout, true);
+}
+
+extern "C" int vsm_release_set(vsm_ctx* c, int set)
+{
+    if (!c) return VSM_EINVAL;
+    if (!get_set(c, set)) return fail(c, VSM_EINVAL, "unknown set id %d", set);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    DescSet& s = c->sets[set];
+    if (s.frag) (void)hipFree(s.frag);
+    if (s.nrm) (void)hipFree(s.nrm);
+    s = DescSet();
+    return VSM_OK;
+}
+
+extern "C" int vsm_set_count(const vsm_ctx* c, int set)
+{
+    const DescSet* s = get_set(c, set);
+    return s ? s->n : VSM_EINVAL;
+}
+
+// ---------------------------------------------------------------------------------
+// f32 helpers (one pair per submission)
+// ---------------------------------------------------------------------------------
+namespace {
+
+struct F32Result {  // device pointers valid until the next submission
+    int32_t *j1, *j2, *cidx;
+    float *k1, *k2, *ck;
+};
+
+int run_f32_knn(vsm_ctx* c, const DescSet* A, const DescSet* B, int metric, bool want_col, F32Result* r)
+{
+    const size_t na = std::max(A->n_pad, 1), nb = std::max(B->n_pad, 1);
+    HIPCHK(c, c->d_knnj.ensure(na * 4));
+    HIPCHK(c, c->d_rrj.ensure(na * 4));
+    HIPCHK(c, c->d_knn1.ensure(na * 4));
+    HIPCHK(c, c->d_knn2.ensure(na * 4));
+    HIPCHK(c, c->d_dense1.ensure(nb * 4));
+    HIPCHK(c, c->d_rr1.ensure(nb * 4));
+    r->j1 = c->d_knnj.as<int32_t>();
+    r->j2 = c->d_rrj.as<int32_t>();
+    r->k1 = c->d_knn1.as<float>();
+    r->k2 = c->d_knn2.as<float>();
+    r->cidx = c->d_dense1.as<int32_t>();
+    r->ck = c->d_rr1.as<float>();
+    c->ev_valid = false;
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    F32Problem pr;
+    pr.fragA = static_cast<const float*>(A->frag);
+    pr.nrmA = static_cast<const float*>(A->nrm);
+    pr.fragB = static_cast<const float*>(B->frag);
+    pr.nrmB = static_cast<const float*>(B->nrm);
+    pr.nA = A->n; pr.nB = B->n; pr.nA_pad = A->n_pad; pr.nB_pad = B->n_pad;
+    pr.dim = A->dim;
+    pr.metric = metric;
+    HIPCHK(c, c->d_colpart.ensure(f32_scratch_bytes(pr, want_col)));
+    launch_f32_knn(pr, r->j1, r->j2, r->k1, r->k2, want_col ? r->cidx : nullptr, want_col ? r->ck : nullptr,
+                   c->d_colpart.p, c->stream);
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        c->ev_valid = true;
+    }
+    HIPCHK(c, hipGetLastError());
+    return VSM_OK;
+}
+
+int match_pair_f32(vsm_ctx* c, const DescSet* A, const DescSet* B, const vsm_params* p, int metric,
+                   int32_t* matches0, int32_t* matches1, float* best0)
+{
+    // dense result on the host; the accept tests are O(n) and run here
+    for (int i = 0; i < A->n; ++i) matches0[i] = -1;
+    if (matches1) for (int j = 0; j < B->n; ++j) matches1[j] = -1;
+    if (A->n == 0 || B->n == 0) return 0;
+    F32Result r;
+    int rc = run_f32_knn(c, A, B, metric, true, &r);
+    if (rc) return rc;
+    std::vector<int32_t> j1(A->n), ci(B->n);
+    std::vector<float> k1(A->n), k2(A->n);
+    HIPCHK(c, hipMemcpyAsync(j1.data(), r.j1, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(k1.data(), r.k1, sizeof(float) * A->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(k2.data(), r.k2, sizeof(float) * A->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ci.data(), r.cidx, sizeof(int32_t) * B->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int nm = 0;
+    for (int i = 0; i < A->n; ++i) {
+        if (best0) best0[i] = k1[i];
+        const int j = j1[i];
+        if (j < 0) continue;
+        bool ok = true;
+        if (metric == VSM_METRIC_DOT) {
+            ok = k1[i] > p->min_score;
+        } else {
+            if (p->max_dist_sq_f >= 0.0f && k1[i] > p->max_dist_sq_f) ok = false;
+            if (ok && p->ratio_num > 0 && B->n >= 2) {
+                const double lhs = (double)k1[i] * (double)p->ratio_den * (double)p->ratio_den;
+                const double rhs = (double)k2[i] * (double)p->ratio_num * (double)p->ratio_num;
+                ok = lhs < rhs;
+            }
+        }
+        if (ok && p->mutual && ci[j] != i) ok = false;
+        if (!ok) continue;
+        matches0[i] = j;
+        if (matches1 && matches1[j] < 0) matches1[j] = i;
+        ++nm;
+    }
+    return nm;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// matching
+// ---------------------------------------------------------------------------------
+extern "C" long long vsm_match_pairs_device(vsm_ctx* c, const int32_t* pairs, int npairs,
+                                            const vsm_params* p, int metric)
+{
+    (void)metric;
+    if (!c) return VSM_EINVAL;
+    if (npairs < 0 || (npairs > 0 && !pairs)) return fail(c, VSM_EINVAL, "bad pair list");
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    Plan pl;
+    if ((rc = plan_u8(c, pairs, npairs, pl)) != VSM_OK) return rc;
+    RunOpts o;
+    if ((rc = run_u8(c, pl, make_rule(p), o)) != VSM_OK) return rc;
+    HIPCHK(c, c->h_small.ensure(64));
+    long long* tot = c->h_small.as<long long>();
+    *tot = 0;
+    if (npairs)
+        HIPCHK(c, hipMemcpyAsync(tot, c->d_offsets.as<int64_t>() + npairs, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->last_npairs = npairs;
+    c->last_total = *tot;
+    return *tot;
+}
+
+extern "C" long long vsm_fetch_matches(vsm_ctx* c, int64_t* offsets, int32_t* idx0, int32_t* idx1, long long cap)
+{
+    if (!c) return VSM_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const long long tot = c->last_total;
+    if (offsets) {
+        if (c->last_npairs)
+            HIPCHK(c, hipMemcpyAsync(offsets, c->d_offsets.p, sizeof(int64_t) * (c->last_npairs + 1), hipMemcpyDeviceToHost, c->stream));
+        else
+            offsets[0] = 0;
+    }
+    if (tot > cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return fail(c, VSM_ECAP, "%lld matches do not fit a buffer of %lld", tot, cap);
+    }
+    if (tot > 0) {
+        if (idx0) HIPCHK(c, hipMemcpyAsync(idx0, c->d_tight0.p, sizeof(int32_t) * tot, hipMemcpyDeviceToHost, c->stream));
+        if (idx1) HIPCHK(c, hipMemcpyAsync(idx1, c->d_tight1.p, sizeof(int32_t) * tot, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return tot;
+}
+
+extern "C" long long vsm_match_pairs(vsm_ctx* c, const int32_t* pairs, int npairs, const vsm_params* p,
+                                     int metric, int64_t* offsets, int32_t* idx0, int32_t* idx1, long long cap)
+{
+    if (!c) return VSM_EINVAL;
+    if (npairs < 0 || (npairs > 0 && !pairs) || !offsets) return fail(c, VSM_EINVAL, "bad pair list or offsets buffer");
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    // cut the list into submissions that fit the scratch budget
+    long long total = 0;
+    int done = 0;
+    offsets[0] = 0;
+    while (done < npairs) {
+        size_t scratch = 0;
+        int take = 0;
+        while (done + take < npairs) {
+            const DescSet* A = get_set(c, pairs[2 * (done + take)]);
+            const DescSet* B = get_set(c, pairs[2 * (done + take) + 1]);
+            if (!A || !B) return fail(c, VSM_EINVAL, "pair %d names an unknown set", done + take);
+            const size_t need = (size_t)(A->n_pad / kStripRows) * B->n_pad * 4;
+            if (take > 0 && (scratch + need > kColpartBudget / 2 || take >= 8192)) break;
+            scratch += need;
+            ++take;
+        }
+        const long long got = vsm_match_pairs_device(c, pairs + 2 * (size_t)done, take, p, metric);
+        if (got < 0) return got;
+        if (total + got > cap) return fail(c, VSM_ECAP, "more than %lld matches", cap);
+        std::vector<int64_t> off(take + 1);
+        const long long f = vsm_fetch_matches(c, off.data(), idx0 ? idx0 + total : nullptr,
+                                              idx1 ? idx1 + total : nullptr, cap - total);
+        if (f < 0) return f;
+        for (int i = 0; i <= take; ++i) offsets[done + i] = total + off[i];
+        total += got;
+        done += take;
+    }
+    return total;
+}
+
+extern "C" int vsm_match_pair(vsm_ctx* c, int set0, int set1, const vsm_params* p, int metric,
+                              int32_t* idx0, int32_t* idx1, void* dist, int cap)
+{
+    if (!c) return VSM_EINVAL;
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    SetKind kind;
+    if ((rc = set_kind_of_pair(c, set0, set1, &kind)) != VSM_OK) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (kind == SET_F32) {
+        const DescSet* A = get_set(c, set0);
+        const DescSet* B = get_set(c, set1);
+        std::vector<int32_t> m0(std::max(A->n, 1));
+        std::vector<float> b0(std::max(A->n, 1));
+        const int nm = match_pair_f32(c, A, B, p, metric, m0.data(), nullptr, b0.data());
+        if (nm < 0) return nm;
+        if (nm > cap) return fail(c, VSM_ECAP, "%d matches do not fit a buffer of %d", nm, cap);
+        int k = 0;
+        for (int i = 0; i < A->n; ++i) {
+            if (m0[i] < 0) continue;
+            if (idx0) idx0[k] = i;
+            if (idx1) idx1[k] = m0[i];
+            if (dist) static_cast<float*>(dist)[k] = b0[i];
+            ++k;
+        }
+        return nm;
+    }
+    const int32_t pr[2] = {set0, set1};
+    Plan pl;
+    if ((rc = plan_u8(c, pr, 1, pl)) != VSM_OK) return rc;
+    RunOpts o;
+    o.want_dist = dist != nullptr;
+    o.want_pack = false;
+    if ((rc = run_u8(c, pl, make_rule(p), o)) != VSM_OK) return rc;
+    HIPCHK(c, c->h_small.ensure(64));
+    int32_t* cnt = c->h_small.as<int32_t>();
+    HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int nm = *cnt;
+    if (nm > cap) return fail(c, VSM_ECAP, "%d matches do not fit a buffer of %d", nm, cap);
+    if (nm > 0) {
+        if (idx0) HIPCHK(c, hipMemcpyAsync(idx0, c->d_slot0.p, sizeof(int32_t) * nm, hipMemcpyDeviceToHost, c->stream));
+        if (idx1) HIPCHK(c, hipMemcpyAsync(idx1, c->d_slot1.p, sizeof(int32_t) * nm, hipMemcpyDeviceToHost, c->stream));
+        if (dist) HIPCHK(c, hipMemcpyAsync(dist, c->d_slotd.p, sizeof(int32_t) * nm, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return nm;
+}
+
+extern "C" int vsm_match_pair_dense(vsm_ctx* c, int set0, int set1, const vsm_params* p, int metric,
+                                    int32_t* matches0, int32_t* matches1)
+{
+    if (!c) return VSM_EINVAL;
+    if (!matches0 || !matches1) return fail(c, VSM_EINVAL, "matches0/matches1 must not be NULL");
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    SetKind kind;
+    if ((rc = set_kind_of_pair(c, set0, set1, &kind)) != VSM_OK) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const DescSet* A = get_set(c, set0);
+    const DescSet* B = get_set(c, set1);
+    if (kind == SET_F32) return match_pair_f32(c, A, B, p, metric, matches0, matches1, nullptr);
+    const int32_t pr[2] = {set0, set1};
+    Plan pl;
+    if ((rc = plan_u8(c, pr, 1, pl)) != VSM_OK) return rc;
+    RunOpts o;
+    o.want_dense = true;
+    o.want_pack = false;
+    if ((rc = run_u8(c, pl, make_rule(p), o)) != VSM_OK) return rc;
+    HIPCHK(c, c->h_small.ensure(64));
+    int32_t* cnt = c->h_small.as<int32_t>();
+    HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (A->n) HIPCHK(c, hipMemcpyAsync(matches0, c->d_dense0.p, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
+    if (B->n) HIPCHK(c, hipMemcpyAsync(matches1, c->d_dense1.p, sizeof(int32_t) * B->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return *cnt;
+}
+
+extern "C" int vsm_knn2(vsm_ctx* c, int set_q, int set_db, int metric,
+                        int32_t* idx1, int32_t* idx2, void* d1, void* d2)
+{
+    if (!c) return VSM_EINVAL;
+    SetKind kind;
+    int rc = set_kind_of_pair(c, set_q, set_db, &kind);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const DescSet* A = get_set(c, set_q);
+    const DescSet* B = get_set(c, set_db);
+    if (A->n == 0) return 0;
+    if (B->n == 0) {
+        for (int i = 0; i < A->n; ++i) {
+            if (idx1) idx1[i] = -1;
+            if (idx2) idx2[i] = -1;
+        }
+        return A->n;
+    }
+    if (kind == SET_F32) {
+        F32Result r;
+        if ((rc = run_f32_knn(c, A, B, metric, false, &r)) != VSM_OK) return rc;
+        if (idx1) HIPCHK(c, hipMemcpyAsync(idx1, r.j1, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
+        if (idx2) HIPCHK(c, hipMemcpyAsync(idx2, r.j2, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
+        if (d1) HIPCHK(c, hipMemcpyAsync(d1, r.k1, sizeof(float) * A->n, hipMemcpyDeviceToHost, c->stream));
+        if (d2) HIPCHK(c, hipMemcpyAsync(d2, r.k2, sizeof(float) * A->n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return A->n;
+    }
+    if (idx2) return fail(c, VSM_EUNSUPPORTED, "the runner-up index is not tracked for u8 sets (pass idx2 = NULL)");
+    const int32_t pr[2] = {set_q, set_db};
+    Plan pl;
+    if ((rc = plan_u8(c, pr, 1, pl)) != VSM_OK) return rc;
+    RunOpts o;
+    o.want_knn = true;
+    o.want_pack = false;
+    MatchRule rule{};
+    rule.num2 = 0; rule.den2 = 1; rule.max_dist = -1; rule.mutual = 0;
+    if ((rc = run_u8(c, pl, rule, o)) != VSM_OK) return rc;
+    if (idx1) HIPCHK(c, hipMemcpyAsync(idx1, c->d_knnj.p, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
+    if (d1) HIPCHK(c, hipMemcpyAsync(d1, c->d_knn1.p, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
+    if (d2) HIPCHK(c, hipMemcpyAsync(d2, c->d_knn2.p, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return A->n;
+}
+
+extern "C" int vsm_merge_top2_f32(const float* k1, const float* k2, const int32_t* i1, const int32_t* i2,
+                                  const int64_t* base, int nslices, int nq, int metric,
+                                  float* ok1, float* ok2, int64_t* oi1, int64_t* oi2)
+{
+    if (!k1 || !k2 || !i1 || !i2 || !base || nslices <= 0 || nq < 0 || !ok1 || !ok2 || !oi1 || !oi2) return VSM_EINVAL;
+    const bool dot = metric == VSM_METRIC_DOT;
+    for (int q = 0; q < nq; ++q) {
+        float b1 = 0, b2 = 0;
+        int64_t x1 = -1, x2 = -1;
+        for (int s = 0; s < nslices; ++s) {
+            for (int r = 0; r < 2; ++r) {
+                const size_t o = (size_t)s * nq + q;
+                const int32_t li = r ? i2[o] : i1[o];
+                if (li < 0) continue;
+                const float k = r ? k2[o] : k1[o];
+                const int64_t id = base[s] + li;
+                auto better = [&](float a, float b) { return dot ? a > b : a < b; };
+                if (x1 < 0 || better(k, b1) || (k == b1 && id < x1)) {
+                    b2 = b1; x2 = x1;
+                    b1 = k; x1 = id;
+                } else if (x2 < 0 || better(k, b2) || (k == b2 && id < x2)) {
+                    b2 = k; x2 = id;
+                }
+            }
+        }
+        ok1[q] = b1; ok2[q] = b2; oi1[q] = x1; oi2[q] = x2;
+    }
+    return VSM_OK;
+}
+
+extern "C" int vsm_nearest_embed(vsm_ctx* c, const float* x, int batch, int dim, int npts,
+                                 const float* emb, int k, int64_t* argmin, float* result)
+{
+    if (!c) return VSM_EINVAL;
+    if (!x || !emb || !argmin || batch < 0 || npts < 0 || k <= 0) return fail(c, VSM_EINVAL, "bad argument");
+    // queries: every (batch, point) column of x; codes: the columns of emb
+    const int code_set = vsm_upload_f32(c, emb, k, dim, VSM_LAYOUT_DIM_MAJOR);
+    if (code_set < 0) return code_set;
+    std::vector<int32_t> idx(std::max(npts, 1));
+    std::vector<float> E;
+    if (result) {
+        E.resize((size_t)k * dim);
+        for (int cc = 0; cc < k; ++cc)
+            for (int d = 0; d < dim; ++d) E[(size_t)cc * dim + d] = emb[(size_t)d * k + cc];
+    }
+    int rc = VSM_OK;
+    for (int b = 0; b < batch && rc >= 0; ++b) {
+        const int qs = vsm_upload_f32(c, x + (size_t)b * dim * npts, npts, dim, VSM_LAYOUT_DIM_MAJOR);
+        if (qs < 0) { rc = qs; break; }
+        rc = vsm_knn2(c, qs, code_set, VSM_METRIC_L2, idx.data(), nullptr, nullptr, nullptr);
+        vsm_release_set(c, qs);
+        if (rc < 0) break;
+        for (int pt = 0; pt < npts; ++pt) {
+            argmin[(size_t)b * npts + pt] = idx[pt];
+            if (result)
+                for (int d = 0; d < dim; ++d)
+                    result[((size_t)b * dim + d) * npts + pt] = E[(size_t)idx[pt] * dim + d];
+        }
+    }
+    vsm_release_set(c, code_set);
+    return rc < 0 ? rc : VSM_OK;
+}

@@ -1,0 +1,178 @@
+"""Host-side mirror of the reference's Python interface around the matcher.
+
+Function names, argument meaning and file output follow
+``Others/SuperPoint_data/main.py`` (the exporter that writes ``matching.txt`` and
+``sift/<i>.txt`` for VisualSfM); the heavy lifting is in libvsm.so.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _binding as B
+
+
+def _b(s):
+    return os.fsencode(s)
+
+
+# ---- pair lists (main.py:157-169) -----------------------------------------------------------
+def generate_imagePairs(list_img, consecutive=3, discrete=(7, 15)):
+    """Pairs (i, i+1..i+consecutive) and (i, i+d) for d in discrete, as [name_i, name_j] lists.
+
+    ``list_img`` plays the role of column 1 of the reference's infor_file.txt."""
+    n = len(list_img)
+    disc = np.ascontiguousarray(list(discrete), dtype=np.int32)
+    cap = n * (consecutive + len(disc)) + 1
+    out = np.empty((cap, 2), np.int32)
+    cnt = B.lib().vsm_image_pairs(n, int(consecutive), B._ptr(disc), len(disc), B._ptr(out), cap)
+    if cnt < 0:
+        raise B.VsmError(cnt, "vsm_image_pairs")
+    return [[list_img[a], list_img[b]] for a, b in out[:cnt]]
+
+
+def generate_exhaustive_pairs(n):
+    """All i < j index pairs, int32 [n(n-1)/2, 2]."""
+    cap = n * (n - 1) // 2
+    out = np.empty((max(cap, 1), 2), np.int32)
+    cnt = B.lib().vsm_image_pairs_exhaustive(int(n), B._ptr(out), cap)
+    if cnt < 0:
+        raise B.VsmError(cnt, "vsm_image_pairs_exhaustive")
+    return out[:cnt]
+
+
+# ---- match txt (main.py:114-155) -------------------------------------------------------------
+def get_list_matching_pairs(matches):
+    """Dense matches (-1 = none) -> (list_0, list_1, number_match) strings as the reference builds them."""
+    matches = np.asarray(matches)
+    length = len(matches)
+    idx0 = np.nonzero(matches != -1)[0]
+    parts0, parts1 = [], []
+    for i in idx0:
+        sep = "" if i == length - 1 else " "
+        parts0.append(str(int(i)) + sep)
+        parts1.append(str(int(matches[i])) + sep)
+    return "".join(parts0), "".join(parts1), len(idx0)
+
+
+def save_matching_sfm(path, matches0, imgPath0, imgPath1):
+    """Appends one ``name0 name1 N / idx0... / idx1...`` record; returns N."""
+    m = np.ascontiguousarray(matches0, dtype=np.int32)
+    rc = B.lib().vsm_matchtxt_append_dense(_b(path), _b(imgPath0), _b(imgPath1), B._ptr(m), len(m))
+    if rc < 0:
+        raise B.VsmError(rc, "vsm_matchtxt_append_dense(%s)" % path)
+    return rc
+
+
+def save_matching_list(path, idx0, idx1, n0, imgPath0, imgPath1):
+    i0 = np.ascontiguousarray(idx0, dtype=np.int32)
+    i1 = np.ascontiguousarray(idx1, dtype=np.int32)
+    rc = B.lib().vsm_matchtxt_append(_b(path), _b(imgPath0), _b(imgPath1), B._ptr(i0), B._ptr(i1), len(i0), int(n0))
+    if rc < 0:
+        raise B.VsmError(rc, "vsm_matchtxt_append(%s)" % path)
+    return rc
+
+
+# ---- keypoint txt (main.py:133-140) ------------------------------------------------------------
+def save_feature_locations(feature_points, path):
+    xy = np.ascontiguousarray(np.asarray(feature_points)[:, :2], dtype=np.float32)
+    rc = B.lib().vsm_feature_txt_write(_b(path), B._ptr(xy), len(xy))
+    if rc < 0:
+        raise B.VsmError(rc, "vsm_feature_txt_write(%s)" % path)
+
+
+def read_feature_locations(path):
+    n = B.lib().vsm_feature_txt_read(_b(path), None, 0)
+    if n < 0:
+        raise B.VsmError(n, "vsm_feature_txt_read(%s)" % path)
+    xy = np.zeros((max(n, 1), 2), np.float32)
+    B.lib().vsm_feature_txt_read(_b(path), B._ptr(xy), n)
+    return xy[:n]
+
+
+# ---- .sift (FeaturePoints.cpp:228-280, 388-446) ---------------------------------------------------
+def read_sift(path, nmax=None):
+    """Returns (loc float32 [n, nloc_dim], des uint8 [n, 128]) or raises."""
+    npoint, nloc = C.c_int(0), C.c_int(0)
+    ok = B.lib().vsm_sift_read(_b(path), None, None, 0, C.byref(npoint), C.byref(nloc))
+    if not ok:
+        raise B.VsmError(-6, "cannot read SIFT file %s" % path)
+    n = npoint.value if nmax is None else min(nmax, npoint.value)
+    loc = np.empty((n, nloc.value), np.float32)
+    des = np.empty((n, 128), np.uint8)
+    ok = B.lib().vsm_sift_read(_b(path), B._ptr(loc), B._ptr(des), n, None, None)
+    if not ok:
+        raise B.VsmError(-6, "short SIFT file %s" % path)
+    return loc, des
+
+
+def write_sift(path, loc, des):
+    loc = np.ascontiguousarray(loc, dtype=np.float32)
+    des = np.ascontiguousarray(des, dtype=np.uint8)
+    if des.ndim != 2 or des.shape[1] != 128 or loc.shape[0] != des.shape[0]:
+        raise ValueError("expected loc [n, d] and des [n, 128]")
+    if not B.lib().vsm_sift_write(_b(path), B._ptr(loc), loc.shape[1], B._ptr(des), des.shape[0]):
+        raise B.VsmError(-5, "cannot write %s" % path)
+
+
+# ---- .mat (MatchFile.cpp:751-958) -------------------------------------------------------------------
+def write_pmatch(image1, image2, fc1, fc2, idx1, idx2, reservation=0):
+    i1 = np.ascontiguousarray(idx1, dtype=np.int32)
+    i2 = np.ascontiguousarray(idx2, dtype=np.int32)
+    rc = B.lib().vsm_mat_write_pmatch(_b(image1), _b(image2), int(fc1), int(fc2), len(i1), B._ptr(i1), B._ptr(i2),
+                                      int(reservation))
+    if rc < 0:
+        raise B.VsmError(rc, "vsm_mat_write_pmatch(%s, %s)" % (image1, image2))
+
+
+def get_pmatch(image, other, fc_other):
+    nm = B.lib().vsm_mat_get_pmatch(_b(image), _b(other), int(fc_other), None, None, 0)
+    a = np.empty(max(nm, 1), np.int32)
+    b = np.empty(max(nm, 1), np.int32)
+    if nm > 0:
+        B.lib().vsm_mat_get_pmatch(_b(image), _b(other), int(fc_other), B._ptr(a), B._ptr(b), nm)
+    return a[:nm], b[:nm]
+
+
+def get_match_count(image, other):
+    nm, nf = C.c_int(0), C.c_int(0)
+    ok = B.lib().vsm_mat_get_match_count(_b(image), _b(other), C.byref(nm), C.byref(nf))
+    return (nm.value, nf.value) if ok else None
+
+
+# ---- float descriptors ---------------------------------------------------------------------------
+def nearest_embed(matcher, x, emb):
+    """Forward of the reference's ``nearest_embed`` (Graph_Idea/model/model_2_0.py:43-78, 102-103):
+    x (batch, emb_dim, *), emb (emb_dim, num_emb) -> (quantised x, argmin)."""
+    return matcher.nearest_embed(x, emb, want_result=True)
+
+
+def mutual_nn_match(matcher, desc0, desc1, match_threshold=0.2, descriptor_dim=None):
+    """The mutual-argmax block of the reference matcher (superglue.py:267-293) applied to the
+    raw score matrix desc0^T desc1 / sqrt(d).  desc0 [d, n], desc1 [d, m] (the reference's
+    native layout).  Returns the same four arrays as the reference's dict."""
+    desc0 = np.ascontiguousarray(desc0, np.float32)
+    desc1 = np.ascontiguousarray(desc1, np.float32)
+    d = desc0.shape[0] if descriptor_dim is None else descriptor_dim
+    scale = 1.0 / float(d) ** 0.5
+    s0 = matcher.upload_f32(desc0, B.LAYOUT_DIM_MAJOR)
+    s1 = matcher.upload_f32(desc1, B.LAYOUT_DIM_MAJOR)
+    try:
+        i0, d0, _ = matcher.knn2(s0, s1, B.METRIC_DOT)
+        i1, d1, _ = matcher.knn2(s1, s0, B.METRIC_DOT)
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)
+    n, m = desc0.shape[1], desc1.shape[1]
+    mutual0 = np.arange(n) == i1[i0]
+    mutual1 = np.arange(m) == i0[i1]
+    mscores0 = np.where(mutual0, np.exp(d0 * np.float32(scale)), np.float32(0)).astype(np.float32)
+    mscores1 = np.where(mutual1, mscores0[i1], np.float32(0)).astype(np.float32)
+    valid0 = mutual0 & (mscores0 > match_threshold)
+    valid1 = mutual1 & valid0[i1]
+    return {
+        "matches0": np.where(valid0, i0, -1).astype(np.int32),
+        "matches1": np.where(valid1, i1, -1).astype(np.int32),
+        "matching_scores0": mscores0,
+        "matching_scores1": mscores1,
+    }
