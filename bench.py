@@ -1,0 +1,373 @@
+#!/usr/bin/env python3
+"""Throughput of the descriptor-matching hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+Default workload = exhaustive SIFT matching (1000 images x 8192 SIFT-128 u8 features, all
+i<j image pairs; ratio 0.8 + mutual check), the configuration the pairs/s and evals/s
+metric is quoted on.  The descriptor arena is generated on the device and is resident in
+HBM before the timed region.  One step = one submission of --pairs-per-step image pairs of
+this rank's shard of the pair list through the whole path (distance kernel, top-2/ratio/
+mutual, compaction, match lists copied back to the host).  Ranks shard the pair list; there
+is no data-path collective.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+INT8_DENSE_PEAK_TOPS = 5000.0   # MI355X dense int8 MFMA, 2x the ~2.5 PFLOP/s bf16 figure
+F32_MFMA_PEAK_TFLOPS = 157.3    # f32-input MFMA (exact f32), = vector peak
+OPS_PER_EVAL_U8 = 256           # 128 multiply-accumulates
+OPS_PER_EVAL_F32 = 512          # 256 fused multiply-adds
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="sift_exhaustive",
+                    choices=["sift_exhaustive", "superpoint_pair", "sift_large_pair", "db_query"])
+    ap.add_argument("--images", type=int, default=1000)
+    ap.add_argument("--features", type=int, default=8192)
+    ap.add_argument("--pairs-per-step", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def dist_setup(args):
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    return torch, dist, world, rank, local
+
+
+def barrier_sync(torch, dist, world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(torch, dist, world, seconds):
+    if world == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(torch, dist, world, v):
+    if world == 1:
+        return v
+    t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gen_sift_arena(torch, nimg, nfeat, seed):
+    """SIFT-like u8 descriptors on the device: |N(0,1)| components, L2-normalised to 512, rounded
+    (the convention of FeaturePoints.cpp:680-684).  30 % of every image's rows are noisy copies of
+    rows of a shared 'scene' pool, so image pairs have real correspondences."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+
+    def raw(n):
+        x = torch.randn((n, 128), generator=g, device="cuda").abs_()
+        x *= 512.0 / x.norm(dim=1, keepdim=True).clamp_min(1e-6)
+        return x
+
+    pool = raw(nfeat)
+    arena = torch.empty((nimg, nfeat, 128), dtype=torch.uint8, device="cuda")
+    k = int(0.3 * nfeat)
+    for i in range(nimg):
+        x = raw(nfeat)
+        src = torch.randperm(nfeat, generator=g, device="cuda")[:k]
+        dst = torch.randperm(nfeat, generator=g, device="cuda")[:k]
+        x[dst] = pool[src] + 6.0 * torch.randn((k, 128), generator=g, device="cuda")
+        arena[i] = x.round_().clamp_(0, 255).to(torch.uint8)
+    torch.cuda.synchronize()
+    return arena
+
+
+def cpu_baseline_u8(a, b, budget_s):
+    """The scalar CPU restatement (oracle) on the host cores: one-directional 2-NN, so its
+    evals are counted exactly like the GPU's."""
+    import oracle_lib as orc
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    rows = min(512, len(a))
+    t0 = time.perf_counter()
+    orc.knn2_u8(a[:rows], b, threads)
+    cal = time.perf_counter() - t0
+    rate = rows * len(b) / max(cal, 1e-6)
+    rows = int(min(len(a), max(rows, rate * budget_s / len(b))))
+    t0 = time.perf_counter()
+    orc.knn2_u8(a[:rows], b, threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": rows * len(b) / dt / 1e9, "unit": "G evals/s", "cores": threads, "kind": "port",
+        "sample": "oracle 2-NN, %d x %d SIFT-128 u8 of the same arena, %.1f s" % (rows, len(b), dt),
+    }
+
+
+def run_sift_exhaustive(args, torch, dist, world, rank):
+    import visual_slam_amd as vsm
+
+    nimg, nfeat, pps = args.images, args.features, args.pairs_per_step
+    arena = gen_sift_arena(torch, nimg, nfeat, seed=1234)
+    m = vsm.Matcher(torch.cuda.current_device())
+    ids = [m.upload_u8_device(arena[i].data_ptr(), nfeat) for i in range(nimg)]
+    pairs_all = vsm.generate_exhaustive_pairs(nimg)
+    # contiguous shard per rank: consecutive pairs share image 0, so it stays cache-resident
+    per = len(pairs_all) // world
+    shard = pairs_all[rank * per:(rank + 1) * per]
+    id_arr = np.asarray(ids, np.int32)
+
+    def step(k):
+        lo = (k * pps) % max(len(shard) - pps + 1, 1)
+        pr = id_arr[shard[lo:lo + pps]]
+        tot = m.match_pairs_device(pr, ratio=0.8, mutual=True)
+        off, i0, i1 = m.fetch_matches(len(pr), tot)
+        return len(pr), tot
+
+    m.set_timing(True)
+    for k in range(args.warmup):
+        step(k)
+    barrier_sync(torch, dist, world)
+    t0 = time.perf_counter()
+    npairs = 0
+    nmatch = 0
+    kernel_ms = []
+    for k in range(args.steps):
+        n, tot = step(args.warmup + k)
+        npairs += n
+        nmatch += tot
+        kernel_ms.append(m.last_kernel_ms())
+    barrier_sync(torch, dist, world)
+    dt = max_over_ranks(torch, dist, world, time.perf_counter() - t0)
+    total_pairs = sum_over_ranks(torch, dist, world, npairs)
+    evals = total_pairs * float(nfeat) * float(nfeat)
+    kms = float(np.mean(kernel_ms))
+    evals_per_launch = float(pps) * nfeat * nfeat
+    achieved = OPS_PER_EVAL_U8 * evals_per_launch / (kms * 1e-3) / 1e12
+    out = {
+        "metric": "descriptor distance evals/sec", "value": evals / dt / 1e9, "unit": "G/s",
+        "pairs_per_s": total_pairs / dt,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "exhaustive SIFT-128 matching, %d images x %d features, ratio 0.8 + mutual, "
+                               "%d pairs per step per GPU, match lists copied to host" % (nimg, nfeat, pps),
+                   "pairs_total": int(len(pairs_all)), "parallelism": "pair list sharded x%d" % world,
+                   "matches_per_pair": nmatch / max(npairs, 1)},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
+                     "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": None,
+                     "kernel": "sift_knn_kernel", "kernel_ms": kms,
+                     "note": "int8 ops: 256 per descriptor pair (128 MAC), one direction counted once"},
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        a = arena[0].cpu().numpy()
+        b = arena[1].cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline_u8(a, b, args.cpu_seconds)
+    m.close()
+    return out
+
+
+def run_superpoint_pair(args, torch, dist, world, rank):
+    """2 images x 4096 SuperPoint-256 float descriptors, mutual nearest neighbour (dot metric)."""
+    import visual_slam_amd as vsm
+    from visual_slam_amd import synth
+
+    n = 4096
+    a, b = synth.superpoint_pair(n, n, 256, seed=77 + rank)
+    m = vsm.Matcher(torch.cuda.current_device())
+    s0, s1 = m.upload_f32(a), m.upload_f32(b)
+    m.set_timing(True)
+
+    def step():
+        return m.match_pair_dense(s0, s1, ratio=None, mutual=True, metric=vsm.METRIC_DOT)
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(torch, dist, world)
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        m0, m1 = step()
+        kernel_ms.append(m.last_kernel_ms())
+    barrier_sync(torch, dist, world)
+    dt = max_over_ranks(torch, dist, world, time.perf_counter() - t0)
+    evals = float(world) * args.steps * n * n
+    kms = float(np.mean(kernel_ms))
+    achieved = OPS_PER_EVAL_F32 * float(n) * n / (kms * 1e-3) / 1e12
+    out = {
+        "metric": "descriptor distance evals/sec", "value": evals / dt / 1e9, "unit": "G/s",
+        "pairs_per_s": world * args.steps / dt,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "SuperPoint-256 f32, 2 images x 4096 keypoints, mutual-NN, one pair per step",
+                   "parallelism": "replicas x%d" % world, "matches": int((m0 >= 0).sum())},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "kernel": "f32_knn_kernel", "kernel_ms": kms,
+                     "note": "exact-f32 MFMA path; includes query merge + train-side merge kernels"},
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle_lib as orc
+        threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0")) or 16, os.cpu_count() or 1))
+        rows = 1024
+        t0 = time.perf_counter()
+        orc.knn2_f32(a[:rows], b, orc.METRIC_DOT, threads)
+        c = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": rows * n / c / 1e9, "unit": "G evals/s", "cores": threads, "kind": "port",
+                               "sample": "oracle 2-NN, %d x %d float-256, %.1f s" % (rows, n, c)}
+    m.close()
+    return out
+
+
+def run_sift_large_pair(args, torch, dist, world, rank):
+    """One pair of 65536 x 65536 SIFT-128 descriptors per step."""
+    import visual_slam_amd as vsm
+
+    n = 65536
+    arena = gen_sift_arena(torch, 2, n, seed=4321 + rank)
+    m = vsm.Matcher(torch.cuda.current_device())
+    ids = [m.upload_u8_device(arena[i].data_ptr(), n) for i in range(2)]
+    m.set_timing(True)
+    pr = np.asarray([[ids[0], ids[1]]], np.int32)
+
+    def step():
+        tot = m.match_pairs_device(pr, ratio=0.8, mutual=True)
+        m.fetch_matches(1, tot)
+        return tot
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(torch, dist, world)
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        tot = step()
+        kernel_ms.append(m.last_kernel_ms())
+    barrier_sync(torch, dist, world)
+    dt = max_over_ranks(torch, dist, world, time.perf_counter() - t0)
+    evals = float(world) * args.steps * n * n
+    kms = float(np.mean(kernel_ms))
+    achieved = OPS_PER_EVAL_U8 * float(n) * n / (kms * 1e-3) / 1e12
+    out = {
+        "metric": "descriptor distance evals/sec", "value": evals / dt / 1e9, "unit": "G/s",
+        "pairs_per_s": world * args.steps / dt,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "one SIFT-128 pair of 65536 x 65536 features, ratio 0.8 + mutual",
+                   "parallelism": "replicas x%d" % world, "matches": int(tot)},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
+                     "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": None,
+                     "kernel": "sift_knn_kernel", "kernel_ms": kms},
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        a = arena[0, :8192].cpu().numpy()
+        b = arena[1, :8192].cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline_u8(a, b, args.cpu_seconds)
+    m.close()
+    return out
+
+
+def run_db_query(args, torch, dist, world, rank):
+    """16384 float-256 queries against a 1M-row database cut into `world` contiguous slices;
+    every rank searches its slice, the per-slice 2-NN lists are all-gathered and merged."""
+    import visual_slam_amd as vsm
+    from visual_slam_amd import _binding as B
+
+    nq, ndb, dim = 16384, 1000000, 256
+    g = torch.Generator(device="cuda")
+    g.manual_seed(99)
+    q = torch.randn((nq, dim), generator=g, device="cuda")
+    q /= q.norm(dim=1, keepdim=True)
+    torch.cuda.synchronize()
+    per = (ndb + world - 1) // world
+    lo, hi = rank * per, min(ndb, (rank + 1) * per)
+    g.manual_seed(1000 + rank)
+    db = torch.randn((hi - lo, dim), generator=g, device="cuda")
+    db /= db.norm(dim=1, keepdim=True)
+    torch.cuda.synchronize()
+    m = vsm.Matcher(torch.cuda.current_device())
+    sq = m.upload_f32_device(q.data_ptr(), nq, dim)
+    sdb = m.upload_f32_device(db.data_ptr(), hi - lo, dim)
+    m.set_timing(True)
+    base = np.asarray([min(ndb, r * per) for r in range(world + 1)], np.int64)
+
+    def step():
+        i1, i2, k1, k2 = m.knn2(sq, sdb, vsm.METRIC_L2, want_idx2=True)
+        if world == 1:
+            return B.merge_top2_f32(k1[None], k2[None], i1[None], i2[None], base, vsm.METRIC_L2)
+        pack = torch.from_numpy(np.stack([k1.view(np.int32), k2.view(np.int32), i1, i2])).cuda()
+        allp = [torch.empty_like(pack) for _ in range(world)]
+        dist.all_gather(allp, pack)
+        allp = torch.stack(allp).cpu().numpy()
+        return B.merge_top2_f32(allp[:, 0].view(np.float32), allp[:, 1].view(np.float32), allp[:, 2], allp[:, 3],
+                                base, vsm.METRIC_L2)
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(torch, dist, world)
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        res = step()
+        kernel_ms.append(m.last_kernel_ms())
+    barrier_sync(torch, dist, world)
+    dt = max_over_ranks(torch, dist, world, time.perf_counter() - t0)
+    evals = float(args.steps) * nq * ndb
+    kms = float(np.mean(kernel_ms))
+    achieved = OPS_PER_EVAL_F32 * float(nq) * (hi - lo) / (kms * 1e-3) / 1e12
+    out = {
+        "metric": "descriptor distance evals/sec", "value": evals / dt / 1e9, "unit": "G/s",
+        "queries_per_s": args.steps * nq / dt,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "16384 float-256 queries vs 1M-row database, k=2, L2",
+                   "parallelism": "database sliced x%d + all-gather + merge" % world},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "kernel": "f32_knn_kernel", "kernel_ms": kms},
+    }
+    m.close()
+    return out
+
+
+def main():
+    args = parse()
+    torch, dist, world, rank, local = dist_setup(args)
+    fn = {"sift_exhaustive": run_sift_exhaustive, "superpoint_pair": run_superpoint_pair,
+          "sift_large_pair": run_sift_large_pair, "db_query": run_db_query}[args.workload]
+    out = fn(args, torch, dist, world, rank)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
