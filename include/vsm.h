@@ -130,6 +130,8 @@ int vsm_nearest_embed(vsm_ctx* ctx, const float* x, int batch, int dim, int npts
  * the context's stream; vsm_last_kernel_ms returns the last bracket (synchronises). */
 int vsm_set_timing(vsm_ctx* ctx, int on);
 float vsm_last_kernel_ms(vsm_ctx* ctx);
+/* Same for the mutual-check pass of a u8 submission (-1 when it did not run). */
+float vsm_last_verify_ms(vsm_ctx* ctx);
 
 /* ---- VisualSfM interchange files (host only, no device needed) ------------------- */
 /* FeatureData::ReadSIFTB(file, locbuf, desbuf, nmax) (FeaturePoints.cpp:516-531) with

@@ -67,6 +67,7 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p]),
     "vsm_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "vsm_last_kernel_ms": (C.c_float, [C.c_void_p]),
+    "vsm_last_verify_ms": (C.c_float, [C.c_void_p]),
     "vsm_sift_read": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vsm_sift_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "vsm_feature_txt_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int]),
@@ -260,6 +261,9 @@ class Matcher:
 
     def last_kernel_ms(self):
         return float(self._l.vsm_last_kernel_ms(self._h))
+
+    def last_verify_ms(self):
+        return float(self._l.vsm_last_verify_ms(self._h))
 
     def synchronize(self):
         self._check(self._l.vsm_synchronize(self._h))

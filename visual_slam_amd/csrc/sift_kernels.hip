@@ -1,10 +1,16 @@
-// SIFT-128 u8 brute-force 2-NN on int8 MFMA (gfx950), with the top-2 selection and the
-// train-side nearest-query reduction fused into the epilogue: the N x M distance matrix
-// never exists in memory.
+// SIFT-128 u8 brute-force matching on int8 MFMA (gfx950).  The N x M distance matrix never
+// exists in memory: the nearest / runner-up selection is fused into the MFMA epilogue.
 //
 // Stands in the position of matching(...) .. get_list_matching_pairs in the reference's
 // per-pair loop (Others/SuperPoint_data/main.py:241-273); the mutual check and the -1
 // convention follow Others/SuperPoint_data/models/superglue.py:276-286.
+//
+// Pipeline per submission of image pairs:
+//   1. query pass   (MFMA)  every image-0 row: nearest image-1 row, distance, runner-up distance
+//   2. select                distance cap + ratio test -> compact candidate list per pair
+//   3. verify pass  (MFMA)  every candidate's image-1 row: nearest image-0 row (mutual check);
+//                            only the candidates' columns are revisited, not the whole matrix
+//   4. confirm               keep candidates whose nearest image-0 row is the candidate itself
 #include "vsm_internal.h"
 
 namespace vsm {
@@ -20,7 +26,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------------
 // One thread per 16-byte chunk of a row (8 threads per row, 8 rows per wave).
 __global__ void sift_transform_kernel(const uint8_t* __restrict__ des, int n, int n_pad,
-                                      int8_t* __restrict__ frag, int32_t* __restrict__ nrm8)
+                                      int8_t* __restrict__ frag, int32_t* __restrict__ nrm8c)
 {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int row = (int)(gid >> 3);
@@ -45,41 +51,41 @@ __global__ void sift_transform_kernel(const uint8_t* __restrict__ des, int n, in
     sum += __shfl_xor(sum, 1);
     sum += __shfl_xor(sum, 2);
     sum += __shfl_xor(sum, 4);
-    if (chunk == 0) nrm8[row] = (row < n) ? (sum << 8) : kNormPad;
+    if (chunk == 0) nrm8c[row] = ((row < n) ? (sum << 8) : kNormPad) | (row & 255);
 }
 
-void launch_sift_transform(const uint8_t* des, int n, int n_pad, int8_t* frag, int32_t* nrm8,
+void launch_sift_transform(const uint8_t* des, int n, int n_pad, int8_t* frag, int32_t* nrm8c,
                            hipStream_t s)
 {
     const long long threads = (long long)n_pad * 8;
     const int block = 256;
     const int grid = (int)((threads + block - 1) / block);
-    hipLaunchKernelGGL(sift_transform_kernel, dim3(grid), dim3(block), 0, s, des, n, n_pad, frag, nrm8);
+    hipLaunchKernelGGL(sift_transform_kernel, dim3(grid), dim3(block), 0, s, des, n, n_pad, frag, nrm8c);
 }
 
 // ---------------------------------------------------------------------------------
-// main kernel
+// streaming MFMA passes
 // ---------------------------------------------------------------------------------
-// Workgroup = 8 waves = one 256-row strip of the query set against one chunk (<= 8192
-// columns) of the train set.  Wave w keeps the MFMA A-operand of its 32 query rows in
-// registers for the whole loop; each step streams a 128-column train tile (16 KiB, already
-// in operand order in HBM) into LDS by LDS-DMA, double buffered, and every wave multiplies
-// its rows by all four 32-column blocks.
+// Workgroup = 8 waves.  Wave w keeps the MFMA operand of 32 "persistent" rows in registers;
+// the other set streams through LDS in 128-row steps (16 KiB, already in operand order in
+// HBM, copied by LDS-DMA, double buffered), and every wave multiplies its 32 rows by all four
+// 32-row tiles of the step.
 //
-// Accumulator layout of v_mfma_i32_32x32x32_i8: lane -> column (lane & 31), register ->
-// row (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  So per lane a query row meets four new
-// columns per step (one per block), and a column meets 16 query rows per block.
+// The persistent rows sit on the accumulator's LANE axis (they are the B operand): lane l owns
+// persistent row (l & 31), and its 16 accumulator registers hold streamed rows
+// (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5) of the tile.  Everything a lane sees therefore
+// belongs to ONE persistent row, so the running minimum lives in two registers per lane and
+// needs no cross-lane traffic until the very end (lanes l and l + 32 hold disjoint streamed
+// rows of the same persistent row).
 //
-// Keys are packed so that one signed 32-bit min carries value and index together:
-//   query side:  x = (nrmB[j] - 2 dot) * 256 + (step * 4 + block)      -> running top-2 / row
-//   train side:  y = (nrmA[i] - 2 dot) * 256 + row-in-strip            -> min over rows
-// (|value| < 2^23, so the product with 256 stays inside int32.)  Ties resolve to the lower
-// index inside a lane; across lanes / strips the finishing code compares (value, index).
-constexpr int kLdsB = 2 * 16384;
-constexpr int kLdsNorm = 2 * 512;
-constexpr int kLdsColmin = kChunkCols * 4;
-constexpr int kLdsTotal = kLdsB + kLdsNorm + kLdsColmin;  // 66560
-static_assert(kLdsTotal >= 256 * 32 * 8, "row merge buffer reuses the front of the LDS block");
+// Keys are packed so one signed 32-bit min carries value and index:
+//     key = (nrm[streamed row] - 2 dot) * 256 + (streamed row & 255)
+// (|value| < 2^23, so the product with 256 stays inside int32; nrm8c already holds
+// nrm * 256 + (row & 255)).  The packed minimum is exact inside a group of 256 streamed rows
+// and resolves ties to the lower row; after every group it is folded into an unpacked running
+// best with a strict compare, which keeps the lower row across groups as well.
+constexpr int kLdsTile = 16384;
+constexpr int kLdsStream = 2 * kLdsTile + 2 * 512;
 
 __device__ __forceinline__ int min3i(int a, int b, int c)
 {
@@ -103,19 +109,60 @@ __device__ __forceinline__ void dma4(const void* gsrc, char* lds_dst)
     __builtin_amdgcn_global_load_lds((const VSM_GLB void*)gsrc, (VSM_LDS void*)lds_dst, 4, 0, 0);
 }
 
+// Blocks b and b + 8 share an XCD (and its L2).  Give every XCD a contiguous range of work
+// items so that the strips of one image pair stream the same set through one L2.
+__device__ __forceinline__ int xcd_contiguous_item(int bid, int nb)
+{
+    const int q = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+    return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+}
+
+// one step's LDS-DMA: 16 KiB of operand-order descriptors + 128 packed norms
+__device__ __forceinline__ void stage_step(char* smem, int buf, const int8_t* frag_src, const int32_t* nrm_src,
+                                           int wave)
+{
+    char* dst = smem + buf * kLdsTile + wave * 2048;
+    dma16(frag_src, dst);
+    dma16(frag_src + 1024, dst + 1024);
+    if (wave < 2) dma4(nrm_src, smem + 2 * kLdsTile + buf * 512 + wave * 256);
+}
+
+// per-tile accumulators of one wave: streamed tile (A operand) x persistent rows (B operand)
+__device__ __forceinline__ v16i tile_dot(const char* tile_lds, const v4i (&pf)[4])
+{
+    const v4i b0 = *reinterpret_cast<const v4i*>(tile_lds);
+    const v4i b1 = *reinterpret_cast<const v4i*>(tile_lds + 1024);
+    const v4i b2 = *reinterpret_cast<const v4i*>(tile_lds + 2048);
+    const v4i b3 = *reinterpret_cast<const v4i*>(tile_lds + 3072);
+    v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b0, pf[0], z, 0, 0, 0);
+    z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b1, pf[1], z, 0, 0, 0);
+    z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b2, pf[2], z, 0, 0, 0);
+    z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b3, pf[3], z, 0, 0, 0);
+    return z;
+}
+
+// the 16 packed norms of the streamed rows this lane's registers hold (4 x 16-byte LDS reads)
+__device__ __forceinline__ void tile_consts(const int* nl_tile, int half, int (&c)[16])
+{
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        const v4i v = *reinterpret_cast<const v4i*>(nl_tile + 8 * qd + 4 * half);
+        c[4 * qd + 0] = v[0];
+        c[4 * qd + 1] = v[1];
+        c[4 * qd + 2] = v[2];
+        c[4 * qd + 3] = v[3];
+    }
+}
+
+// ---- 1. query pass ------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2)
-void sift_knn_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ items,
-                     int32_t* __restrict__ rr_d1, int32_t* __restrict__ rr_j1,
-                     int32_t* __restrict__ rr_d2, int32_t* __restrict__ colpart, int negscale)
+void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ items,
+                       int32_t* __restrict__ rr_d1, int32_t* __restrict__ rr_j1,
+                       int32_t* __restrict__ rr_d2, int negscale)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    // Blocks b and b + 8 share an XCD (and its L2).  Give every XCD a contiguous range of
-    // work items so the 32 strips of one pair stream the same train set through one L2.
-    const int nb = gridDim.x, bid = blockIdx.x;
-    const int q = nb >> 3, r8 = nb & 7, xcd = bid & 7;
-    const int L = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const SiftItem it = items[L];
+    const SiftItem it = items[xcd_contiguous_item(blockIdx.x, gridDim.x)];
     const SiftPair pw = pairs[it.pair];
 
     const int tid = threadIdx.x;
@@ -126,179 +173,220 @@ void sift_knn_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restr
 
     const int c0 = it.chunk * kChunkCols;
     const int ncols = min(kChunkCols, pw.nB_pad - c0);
-    const int nsteps = ncols / kStepCols;
+    const int nsteps = ncols / kStepRows;  // even: sets are padded to 256 rows
 
-    int* colmin = reinterpret_cast<int*>(smem + kLdsB + kLdsNorm);
-    for (int t = tid; t < ncols; t += 512) colmin[t] = INT32_MAX;
-
-    // persistent A operand and per-row constants
-    const int rowbase = it.strip * kStripRows + wave * 32;
-    const int8_t* Abase = pw.fragA + (size_t)(rowbase >> 5) * kTileBytes + lane * 16;
-    v4i a[4];
+    // persistent operand: this wave's 32 query rows
+    const int qtile = it.strip * (kStripRows / 32) + wave;
+    v4i pf[4];
+    {
+        const int8_t* src = pw.fragA + (size_t)qtile * kTileBytes + lane * 16;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const v4i*>(Abase + s * 1024);
-    int rc[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int rin = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-        rc[reg] = pw.nrmA[rowbase + rin] + (wave * 32 + rin);
+        for (int s = 0; s < 4; ++s) pf[s] = *reinterpret_cast<const v4i*>(src + s * 1024);
     }
-    int k1[16], k2[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) { k1[reg] = INT32_MAX; k2[reg] = INT32_MAX; }
 
     const int8_t* Bsrc = pw.fragB + (size_t)(c0 >> 5) * kTileBytes + wave * 2048 + lane * 16;
     const int32_t* Nsrc = pw.nrmB + c0 + (wave & 1) * 64 + lane;
 
-    // prologue: stage step 0
-    {
-        char* dst = smem + wave * 2048;
-        dma16(Bsrc, dst);
-        dma16(Bsrc + 1024, dst + 1024);
-        if (wave < 2) dma4(Nsrc, smem + kLdsB + wave * 256);
-    }
+    int k1 = INT32_MAX, k2 = INT32_MAX;            // packed, current 256-column group
+    int bestd = kDistPad, bestcol = INT32_MAX, second = kDistPad;  // unpacked running result
+
+    stage_step(smem, 0, Bsrc, Nsrc, wave);
     __syncthreads();
 
     for (int st = 0; st < nsteps; ++st) {
         const int cur = st & 1;
-        if (st + 1 < nsteps) {
-            char* dst = smem + (cur ^ 1) * 16384 + wave * 2048;
-            const int8_t* src = Bsrc + (size_t)(st + 1) * 16384;
-            dma16(src, dst);
-            dma16(src + 1024, dst + 1024);
-            if (wave < 2) dma4(Nsrc + (st + 1) * kStepCols, smem + kLdsB + (cur ^ 1) * 512 + wave * 256);
-        }
-        const char* Bt = smem + cur * 16384 + lane * 16;
-        const int* nl = reinterpret_cast<const int*>(smem + kLdsB + cur * 512);
+        if (st + 1 < nsteps)
+            stage_step(smem, cur ^ 1, Bsrc + (size_t)(st + 1) * kLdsTile, Nsrc + (st + 1) * kStepRows, wave);
+        const char* Bt = smem + cur * kLdsTile + lane * 16;
+        const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * 512);
 
-        v16i acc[4];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            v4i b0 = *reinterpret_cast<const v4i*>(Bt + cb * 4096);
-            v4i b1 = *reinterpret_cast<const v4i*>(Bt + cb * 4096 + 1024);
-            v4i b2 = *reinterpret_cast<const v4i*>(Bt + cb * 4096 + 2048);
-            v4i b3 = *reinterpret_cast<const v4i*>(Bt + cb * 4096 + 3072);
-            v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            z = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b0, z, 0, 0, 0);
-            z = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1], b1, z, 0, 0, 0);
-            z = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[2], b2, z, 0, 0, 0);
-            z = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[3], b3, z, 0, 0, 0);
-            acc[cb] = z;
-        }
-
-        int cj[4], cm[4];
+        for (int t = 0; t < 4; ++t) {
+            const v16i acc = tile_dot(Bt + t * 4096, pf);
+            int c[16];
+            tile_consts(nl + t * 32, half, c);
+            int u[8];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            cj[cb] = nl[cb * 32 + lane5] + (st * 4 + cb);
-            asm volatile("" : "+v"(cj[cb]));  // keep the sum formed once, outside the mads
-            cm[cb] = INT32_MAX;
-        }
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int x0 = __mul24(acc[0][reg], negscale) + cj[0];
-            const int x1 = __mul24(acc[1][reg], negscale) + cj[1];
-            const int x2 = __mul24(acc[2][reg], negscale) + cj[2];
-            const int x3 = __mul24(acc[3][reg], negscale) + cj[3];
-            // running two smallest of {k1, k2, x0..x3}
-            const int ua = med3i(k1[reg], x0, x1);
-            const int ka = min3i(k1[reg], x0, x1);
-            const int ub = med3i(ka, x2, x3);
-            k1[reg] = min3i(ka, x2, x3);
-            k2[reg] = min3i(k2[reg], ua, ub);
-        }
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-#pragma unroll
-            for (int reg = 0; reg < 16; reg += 2) {
-                const int y0 = __mul24(acc[cb][reg], negscale) + rc[reg];
-                const int y1 = __mul24(acc[cb][reg + 1], negscale) + rc[reg + 1];
-                cm[cb] = min3i(cm[cb], y0, y1);
+            for (int e = 0; e < 8; ++e) {
+                const int x0 = __mul24(acc[2 * e], negscale) + c[2 * e];
+                const int x1 = __mul24(acc[2 * e + 1], negscale) + c[2 * e + 1];
+                u[e] = med3i(k1, x0, x1);   // runner-up of {k1, x0, x1}
+                k1 = min3i(k1, x0, x1);
             }
-            atomicMin(&colmin[st * kStepCols + cb * 32 + lane5], cm[cb]);
+            k2 = min3i(k2, u[0], u[1]);
+            k2 = min3i(k2, u[2], u[3]);
+            k2 = min3i(k2, u[4], u[5]);
+            k2 = min3i(k2, u[6], u[7]);
+        }
+        if (st & 1) {
+            // fold the finished 256-column group into the running result
+            const int d = k1 >> 8;
+            const int col = c0 + (st - 1) * kStepRows + (k1 & 255);
+            if (d < bestd) {
+                second = min(second, bestd);
+                bestd = d;
+                bestcol = col;
+            } else {
+                second = min(second, d);
+            }
+            second = min(second, k2 >> 8);
+            k1 = INT32_MAX;
+            k2 = INT32_MAX;
         }
         __syncthreads();
     }
 
-    // train-side partial minima of this strip
+    // lanes l and l + 32 saw disjoint columns of the same query row
     {
-        int32_t* dst = colpart + pw.col_off + (size_t)it.strip * pw.nB_pad + c0;
-        for (int t = tid; t < ncols; t += 512) dst[t] = colmin[t];
-    }
-    __syncthreads();
-
-    // query-side: merge the 32 per-lane candidates of every row
-    int2* rowbuf = reinterpret_cast<int2*>(smem);  // [256][32]
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int rin = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-        rowbuf[(wave * 32 + rin) * 32 + lane5] = make_int2(k1[reg], k2[reg]);
-    }
-    __syncthreads();
-    {
-        const int row = tid >> 1, part = tid & 1;
-        long long best = INT64_MAX;
-        int second = kDistPad;
-        for (int e = 0; e < 16; ++e) {
-            const int l5 = part * 16 + e;
-            const int2 kk = rowbuf[row * 32 + l5];
-            const int idx8 = kk.x & 255;
-            const int col = c0 + (idx8 >> 2) * kStepCols + (idx8 & 3) * 32 + l5;
-            const int d = kk.x >> 8;
-            const long long comp = (long long)d * 4294967296LL + (unsigned)col;
-            if (comp < best) {
-                second = min(second, (int)(best >> 32));
-                best = comp;
-            } else {
-                second = min(second, d);
-            }
-            second = min(second, kk.y >> 8);
+        const int od = __shfl_xor(bestd, 32);
+        const int oc = __shfl_xor(bestcol, 32);
+        const int os = __shfl_xor(second, 32);
+        const bool other_wins = od < bestd || (od == bestd && oc < bestcol);
+        const int loser = other_wins ? bestd : od;
+        if (other_wins) {
+            bestd = od;
+            bestcol = oc;
         }
-        // combine the two half-rows (neighbouring lanes)
-        const long long obest = __shfl_xor(best, 1);
-        const int osecond = __shfl_xor(second, 1);
-        const long long lo = best < obest ? best : obest;
-        const long long hi = best < obest ? obest : best;
-        second = min(min(second, osecond), (int)(hi >> 32));
-        if (part == 0) {
-            const int grow = it.strip * kStripRows + row;
-            const int na = pw.nrmA[grow] >> 8;
-            const size_t o = pw.row_off + (size_t)it.chunk * pw.nA_pad + grow;
-            const int d1 = (int)(lo >> 32);
-            rr_d1[o] = d1 >= kDistPad ? INT32_MAX : d1 + na;
-            rr_j1[o] = (int)(unsigned)(lo & 0xffffffffu);
-            rr_d2[o] = second >= kDistPad ? INT32_MAX : second + na;
-        }
+        second = min(min(second, os), loser);
+    }
+    if (half == 0) {
+        const int grow = qtile * 32 + lane5;
+        const int na = pw.nrmA[grow] >> 8;
+        const size_t o = pw.row_off + (size_t)it.chunk * pw.nA_pad + grow;
+        rr_d1[o] = bestd >= kDistPad ? INT32_MAX : bestd + na;
+        rr_j1[o] = bestcol;
+        rr_d2[o] = second >= kDistPad ? INT32_MAX : second + na;
     }
 }
 
-void launch_sift_knn(const SiftPair* pairs, const SiftItem* items, int nitems,
-                     int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, int32_t* colpart,
-                     hipStream_t s)
+void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
+                       int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(sift_knn_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
-        attr_set = true;
+    hipLaunchKernelGGL(sift_query_kernel, dim3(nitems), dim3(512), kLdsStream, s,
+                       pairs, items, rr_d1, rr_j1, rr_d2, -512);
+}
+
+// ---- 3. verify pass -------------------------------------------------------------------
+// Persistent rows = the image-1 rows named by a block of 256 candidates (gathered from the
+// operand-order layout); streamed set = all of image 0.  Per candidate: the nearest image-0 row.
+__global__ __launch_bounds__(512, 2)
+void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ vitems,
+                        SiftCandidates cand, int negscale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SiftItem it = vitems[xcd_contiguous_item(blockIdx.x, gridDim.x)];
+    const SiftPair pw = pairs[it.pair];
+    const int ncand = cand.count[it.pair];
+    const int cbase = it.strip * kStripRows;
+    if (cbase >= ncand) return;  // uniform for the whole workgroup
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane5 = lane & 31;
+    const int half = lane >> 5;
+
+    const int ci = cbase + wave * 32 + lane5;
+    const bool valid = ci < ncand;
+    const int j = valid ? cand.j1[pw.out0_off + ci] : 0;
+    v4i pf[4];
+    {
+        const int8_t* src = pw.fragB + (size_t)(j >> 5) * kTileBytes + (half * 32 + (j & 31)) * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pf[s] = *reinterpret_cast<const v4i*>(src + s * 1024);
     }
-    hipLaunchKernelGGL(sift_knn_kernel, dim3(nitems), dim3(512), kLdsTotal, s,
-                       pairs, items, rr_d1, rr_j1, rr_d2, colpart, -512);
+
+    const int nsteps = pw.nA_pad / kStepRows;
+    const int8_t* Asrc = pw.fragA + wave * 2048 + lane * 16;
+    const int32_t* Nsrc = pw.nrmA + (wave & 1) * 64 + lane;
+
+    int m = INT32_MAX;
+    int bestd = kDistPad, bestrow = INT32_MAX;
+
+    stage_step(smem, 0, Asrc, Nsrc, wave);
+    __syncthreads();
+
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nsteps)
+            stage_step(smem, cur ^ 1, Asrc + (size_t)(st + 1) * kLdsTile, Nsrc + (st + 1) * kStepRows, wave);
+        const char* At = smem + cur * kLdsTile + lane * 16;
+        const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * 512);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const v16i acc = tile_dot(At + t * 4096, pf);
+            int c[16];
+            tile_consts(nl + t * 32, half, c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int y0 = __mul24(acc[2 * e], negscale) + c[2 * e];
+                const int y1 = __mul24(acc[2 * e + 1], negscale) + c[2 * e + 1];
+                m = min3i(m, y0, y1);
+            }
+        }
+        if (st & 1) {
+            const int d = m >> 8;
+            if (d < bestd) {
+                bestd = d;
+                bestrow = (st - 1) * kStepRows + (m & 255);
+            }
+            m = INT32_MAX;
+        }
+        __syncthreads();
+    }
+    {
+        const int od = __shfl_xor(bestd, 32);
+        const int orow = __shfl_xor(bestrow, 32);
+        if (od < bestd || (od == bestd && orow < bestrow)) {
+            bestd = od;
+            bestrow = orow;
+        }
+    }
+    if (half == 0 && valid) cand.vrow[pw.out0_off + ci] = bestrow;
+}
+
+void launch_sift_verify(const SiftPair* pairs, const SiftItem* vitems, int nvitems,
+                        SiftCandidates cand, hipStream_t s)
+{
+    hipLaunchKernelGGL(sift_verify_kernel, dim3(nvitems), dim3(512), kLdsStream, s,
+                       pairs, vitems, cand, -512);
 }
 
 // ---------------------------------------------------------------------------------
-// finishing kernel: chunk merge, train-side strip merge, tests, compaction
+// block-wide compaction helper (1024 threads)
 // ---------------------------------------------------------------------------------
+// returns this thread's output slot (valid if flag) and advances *base_s by the block total
+__device__ __forceinline__ int block_compact_slot(bool flag, int* wsum, int* base_s)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+        const int c = wsum[w];
+        if (w < wave) woff += c;
+        tot += c;
+    }
+    const int base = *base_s;
+    __syncthreads();
+    if (tid == 0) *base_s = base + tot;
+    __syncthreads();
+    return base + woff + before;
+}
+
+// ---- 2. select ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024)
-void sift_finalize_kernel(const SiftPair* __restrict__ pairs,
-                          const int32_t* __restrict__ rr_d1, const int32_t* __restrict__ rr_j1,
-                          const int32_t* __restrict__ rr_d2, const int32_t* __restrict__ colpart,
-                          MatchRule rule, SiftOutputs out)
+void sift_select_kernel(const SiftPair* __restrict__ pairs,
+                        const int32_t* __restrict__ rr_d1, const int32_t* __restrict__ rr_j1,
+                        const int32_t* __restrict__ rr_d2, MatchRule rule,
+                        SiftCandidates cand, SiftOutputs out)
 {
     __shared__ int wsum[16];
     __shared__ int base_s;
     const SiftPair pw = pairs[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
+    const int tid = threadIdx.x;
     if (tid == 0) base_s = 0;
     __syncthreads();
 
@@ -307,8 +395,7 @@ void sift_finalize_kernel(const SiftPair* __restrict__ pairs,
         int j1 = -1, d1 = INT32_MAX, d2 = INT32_MAX;
         bool ok = false;
         if (i < pw.nA) {
-            // merge chunks (chunk order = ascending column index, so a strict compare
-            // keeps the lowest column on ties)
+            // merge chunks (ascending column ranges: a strict compare keeps the lowest column)
             for (int c = 0; c < pw.nchunks; ++c) {
                 const size_t o = pw.row_off + (size_t)c * pw.nA_pad + i;
                 const int e1 = rr_d1[o], ej = rr_j1[o], e2 = rr_d2[o];
@@ -320,7 +407,7 @@ void sift_finalize_kernel(const SiftPair* __restrict__ pairs,
                     d2 = min(d2, e1);
                 }
             }
-            if (j1 >= pw.nB) j1 = -1;  // only padding was seen (cannot happen for nB >= 1)
+            if (j1 >= pw.nB) j1 = -1;
             ok = j1 >= 0;
             if (out.knn_j1) {
                 out.knn_j1[pw.out0_off + i] = j1;
@@ -331,72 +418,76 @@ void sift_finalize_kernel(const SiftPair* __restrict__ pairs,
             if (ok && rule.num2 > 0 && d2 != INT32_MAX) {
                 if (!((long long)d1 * rule.den2 < (long long)d2 * rule.num2)) ok = false;
             }
-            if (ok && rule.mutual) {
-                // nearest query row of column j1: min over strips of (value, row)
-                long long best = INT64_MAX;
-                for (int s = 0; s < pw.nstrips; ++s) {
-                    const int key = colpart[pw.col_off + (size_t)s * pw.nB_pad + j1];
-                    const long long comp = (long long)(key >> 8) * 4294967296LL +
-                                           (unsigned)(s * kStripRows + (key & 255));
-                    best = comp < best ? comp : best;
-                }
-                ok = (int)(unsigned)(best & 0xffffffffu) == i;
-            }
-            if (out.dense0) out.dense0[pw.out0_off + i] = ok ? j1 : -1;
         }
-        // block-wide exclusive scan of ok
-        const unsigned long long bal = __ballot(ok);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __popcll(bal);
-        __syncthreads();
-        int woff = 0, tot = 0;
-        for (int w = 0; w < 16; ++w) {
-            const int c = wsum[w];
-            if (w < wave) woff += c;
-            tot += c;
-        }
-        const int base = base_s;
+        const int slot = block_compact_slot(ok, wsum, &base_s);
         if (ok) {
-            const size_t o = pw.out0_off + base + woff + before;
-            out.slot_i0[o] = i;
-            out.slot_i1[o] = j1;
-            if (out.slot_d) out.slot_d[o] = d1;
+            const size_t o = pw.out0_off + slot;
+            cand.i0[o] = i;
+            cand.j1[o] = j1;
+            cand.d1[o] = d1;
         }
-        __syncthreads();
-        if (tid == 0) base_s = base + tot;
-        __syncthreads();
     }
-    if (tid == 0) out.counts[blockIdx.x] = base_s;
+    __syncthreads();
+    if (tid == 0) cand.count[blockIdx.x] = base_s;
 }
 
-// dense1[j] = lowest query row matched to train row j (a second pass keeps it simple and
-// deterministic; with the mutual check at most one query row maps to each j anyway)
-__global__ void sift_dense1_kernel(const SiftPair* __restrict__ pairs, const int32_t* __restrict__ counts,
-                                   const int32_t* __restrict__ slot_i0, const int32_t* __restrict__ slot_i1,
-                                   int32_t* __restrict__ dense1)
+void launch_sift_select(const SiftPair* pairs, int npairs, const int32_t* rr_d1, const int32_t* rr_j1,
+                        const int32_t* rr_d2, MatchRule rule, SiftCandidates cand, SiftOutputs out,
+                        hipStream_t s)
 {
+    hipLaunchKernelGGL(sift_select_kernel, dim3(npairs), dim3(1024), 0, s,
+                       pairs, rr_d1, rr_j1, rr_d2, rule, cand, out);
+}
+
+// ---- 4. confirm --------------------------------------------------------------------------
+__global__ __launch_bounds__(1024)
+void sift_confirm_kernel(const SiftPair* __restrict__ pairs, SiftCandidates cand, int mutual, SiftOutputs out)
+{
+    __shared__ int wsum[16];
+    __shared__ int base_s;
     const SiftPair pw = pairs[blockIdx.x];
-    const int cnt = counts[blockIdx.x];
-    for (int t = threadIdx.x; t < pw.nB; t += blockDim.x) dense1[pw.out1_off + t] = INT32_MAX;
+    const int tid = threadIdx.x;
+    const int ncand = cand.count[blockIdx.x];
+    if (tid == 0) base_s = 0;
+    if (out.dense0)
+        for (int i = tid; i < pw.nA; i += 1024) out.dense0[pw.out0_off + i] = -1;
+    if (out.dense1)
+        for (int jj = tid; jj < pw.nB; jj += 1024) out.dense1[pw.out1_off + jj] = INT32_MAX;
     __syncthreads();
-    for (int t = threadIdx.x; t < cnt; t += blockDim.x)
-        atomicMin(&dense1[pw.out1_off + slot_i1[pw.out0_off + t]], slot_i0[pw.out0_off + t]);
+
+    for (int c0 = 0; c0 < ncand; c0 += 1024) {
+        const int c = c0 + tid;
+        int i = 0, j = 0, d = 0;
+        bool ok = false;
+        if (c < ncand) {
+            const size_t o = pw.out0_off + c;
+            i = cand.i0[o];
+            j = cand.j1[o];
+            d = cand.d1[o];
+            ok = !mutual || cand.vrow[o] == i;
+        }
+        const int slot = block_compact_slot(ok, wsum, &base_s);
+        if (ok) {
+            const size_t o = pw.out0_off + slot;
+            out.slot_i0[o] = i;
+            out.slot_i1[o] = j;
+            if (out.slot_d) out.slot_d[o] = d;
+            if (out.dense0) out.dense0[pw.out0_off + i] = j;
+            // without the mutual check several rows may name one train row: report the lowest
+            if (out.dense1) atomicMin(&out.dense1[pw.out1_off + j], i);
+        }
+    }
     __syncthreads();
-    for (int t = threadIdx.x; t < pw.nB; t += blockDim.x)
-        if (dense1[pw.out1_off + t] == INT32_MAX) dense1[pw.out1_off + t] = -1;
+    if (tid == 0) out.counts[blockIdx.x] = base_s;
+    if (out.dense1)
+        for (int jj = tid; jj < pw.nB; jj += 1024)
+            if (out.dense1[pw.out1_off + jj] == INT32_MAX) out.dense1[pw.out1_off + jj] = -1;
 }
 
-void launch_sift_finalize(const SiftPair* pairs, int npairs,
-                          const int32_t* rr_d1, const int32_t* rr_j1, const int32_t* rr_d2,
-                          const int32_t* colpart, MatchRule rule, SiftOutputs out, hipStream_t s)
+void launch_sift_confirm(const SiftPair* pairs, int npairs, SiftCandidates cand, int mutual,
+                         SiftOutputs out, hipStream_t s)
 {
-    int32_t* dense1 = out.dense1;
-    out.dense1 = nullptr;  // filled by the second pass below
-    hipLaunchKernelGGL(sift_finalize_kernel, dim3(npairs), dim3(1024), 0, s,
-                       pairs, rr_d1, rr_j1, rr_d2, colpart, rule, out);
-    if (dense1)
-        hipLaunchKernelGGL(sift_dense1_kernel, dim3(npairs), dim3(1024), 0, s,
-                           pairs, out.counts, out.slot_i0, out.slot_i1, dense1);
+    hipLaunchKernelGGL(sift_confirm_kernel, dim3(npairs), dim3(1024), 0, s, pairs, cand, mutual, out);
 }
 
 // ---------------------------------------------------------------------------------

@@ -83,7 +83,7 @@ struct vsm_ctx {
     std::string err;
     std::vector<DescSet> sets;
     // workspace (grow-only)
-    DevBuf d_pairs, d_items, d_rr1, d_rrj, d_rr2, d_colpart;
+    DevBuf d_pairs, d_items, d_rr1, d_rrj, d_rr2, d_colpart, d_cand;
     DevBuf d_slot0, d_slot1, d_slotd, d_counts, d_offsets, d_tight0, d_tight1;
     DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage;
     HostBuf h_pairs, h_items, h_small;
@@ -92,8 +92,8 @@ struct vsm_ctx {
     long long last_total = 0;
     // timing
     int timing = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    bool ev_valid = false, ev_verify_valid = false;
 };
 
 namespace {
@@ -142,19 +142,23 @@ int check_params(vsm_ctx* c, const vsm_params* p)
     return VSM_OK;
 }
 
-// One submission must fit this much scratch for the per-strip train-side partial minima.
-constexpr size_t kColpartBudget = (size_t)12 << 30;
+// One submission may use this many bytes of per-row scratch (partial results, candidate and
+// output lists: about 40 bytes per image-0 row).
+constexpr size_t kScratchBudget = (size_t)8 << 30;
+constexpr size_t kScratchPerRow = 40;
 
 struct Plan {
     std::vector<SiftPair> pairs;
-    std::vector<SiftItem> items;
-    size_t rows = 0, cols = 0, out0 = 0, out1 = 0;
+    std::vector<SiftItem> items;   // query pass: (pair, strip, chunk)
+    std::vector<SiftItem> vitems;  // verify pass: (pair, block of 256 candidates)
+    size_t rows = 0, out0 = 0, out1 = 0;
 };
 
 int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
 {
     pl.pairs.resize(npairs);
     pl.items.clear();
+    pl.vitems.clear();
     for (int p = 0; p < npairs; ++p) {
         const DescSet* A = get_set(c, pairs[2 * p]);
         const DescSet* B = get_set(c, pairs[2 * p + 1]);
@@ -170,19 +174,19 @@ int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
         sp.nstrips = empty ? 0 : A->n_pad / kStripRows;
         sp.nchunks = empty ? 0 : (B->n_pad + kChunkCols - 1) / kChunkCols;
         sp.row_off = (int64_t)pl.rows;
-        sp.col_off = (int64_t)pl.cols;
         sp.out0_off = (int64_t)pl.out0;
         sp.out1_off = (int64_t)pl.out1;
         pl.rows += (size_t)sp.nchunks * sp.nA_pad;
-        pl.cols += (size_t)sp.nstrips * sp.nB_pad;
         pl.out0 += (size_t)sp.nA;
         pl.out1 += (size_t)sp.nB;
-        for (int s = 0; s < sp.nstrips; ++s)
+        for (int s = 0; s < sp.nstrips; ++s) {
             for (int ch = 0; ch < sp.nchunks; ++ch) pl.items.push_back(SiftItem{p, (int16_t)s, (int16_t)ch});
+            pl.vitems.push_back(SiftItem{p, (int16_t)s, 0});
+        }
     }
-    if (pl.cols * 4 > kColpartBudget)
-        return fail(c, VSM_EINVAL, "submission needs %zu bytes of scratch (limit %zu); submit fewer pairs per call",
-                    pl.cols * 4, kColpartBudget);
+    if ((pl.rows + pl.out0) * kScratchPerRow > kScratchBudget)
+        return fail(c, VSM_EINVAL, "submission needs about %zu bytes of scratch (limit %zu); submit fewer pairs per call",
+                    (pl.rows + pl.out0) * kScratchPerRow, kScratchBudget);
     return VSM_OK;
 }
 
@@ -195,16 +199,17 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
 {
     const int npairs = (int)pl.pairs.size();
     const int nitems = (int)pl.items.size();
+    const int nvitems = rule.mutual ? (int)pl.vitems.size() : 0;
     HIPCHK(c, c->h_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
-    HIPCHK(c, c->h_items.ensure(sizeof(SiftItem) * std::max(nitems, 1)));
+    HIPCHK(c, c->h_items.ensure(sizeof(SiftItem) * std::max(nitems + nvitems, 1)));
     HIPCHK(c, c->d_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
-    HIPCHK(c, c->d_items.ensure(sizeof(SiftItem) * std::max(nitems, 1)));
-    const size_t rows = std::max<size_t>(pl.rows, 1), cols = std::max<size_t>(pl.cols, 1);
+    HIPCHK(c, c->d_items.ensure(sizeof(SiftItem) * std::max(nitems + nvitems, 1)));
+    const size_t rows = std::max<size_t>(pl.rows, 1);
     const size_t out0 = std::max<size_t>(pl.out0, 1), out1 = std::max<size_t>(pl.out1, 1);
     HIPCHK(c, c->d_rr1.ensure(rows * 4));
     HIPCHK(c, c->d_rrj.ensure(rows * 4));
     HIPCHK(c, c->d_rr2.ensure(rows * 4));
-    HIPCHK(c, c->d_colpart.ensure(cols * 4));
+    HIPCHK(c, c->d_cand.ensure(out0 * 16 + sizeof(int32_t) * std::max(npairs, 1)));
     HIPCHK(c, c->d_slot0.ensure(out0 * 4));
     HIPCHK(c, c->d_slot1.ensure(out0 * 4));
     if (o.want_dist) HIPCHK(c, c->d_slotd.ensure(out0 * 4));
@@ -227,21 +232,29 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (npairs) memcpy(c->h_pairs.p, pl.pairs.data(), sizeof(SiftPair) * npairs);
     if (nitems) memcpy(c->h_items.p, pl.items.data(), sizeof(SiftItem) * nitems);
+    if (nvitems) memcpy(c->h_items.as<SiftItem>() + nitems, pl.vitems.data(), sizeof(SiftItem) * nvitems);
     if (npairs) HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->h_pairs.p, sizeof(SiftPair) * npairs, hipMemcpyHostToDevice, c->stream));
-    if (nitems) HIPCHK(c, hipMemcpyAsync(c->d_items.p, c->h_items.p, sizeof(SiftItem) * nitems, hipMemcpyHostToDevice, c->stream));
+    if (nitems + nvitems)
+        HIPCHK(c, hipMemcpyAsync(c->d_items.p, c->h_items.p, sizeof(SiftItem) * (nitems + nvitems), hipMemcpyHostToDevice, c->stream));
 
     c->ev_valid = false;
+    c->ev_verify_valid = false;
     if (nitems) {
         if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-        launch_sift_knn(c->d_pairs.as<SiftPair>(), c->d_items.as<SiftItem>(), nitems,
-                        c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(),
-                        c->d_colpart.as<int32_t>(), c->stream);
+        launch_sift_query(c->d_pairs.as<SiftPair>(), c->d_items.as<SiftItem>(), nitems,
+                          c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), c->stream);
         if (c->timing) {
             HIPCHK(c, hipEventRecord(c->ev1, c->stream));
             c->ev_valid = true;
         }
     }
     if (npairs) {
+        SiftCandidates cand{};
+        cand.i0 = c->d_cand.as<int32_t>();
+        cand.j1 = cand.i0 + out0;
+        cand.d1 = cand.j1 + out0;
+        cand.vrow = cand.d1 + out0;
+        cand.count = cand.vrow + out0;
         SiftOutputs out{};
         out.slot_i0 = c->d_slot0.as<int32_t>();
         out.slot_i1 = c->d_slot1.as<int32_t>();
@@ -256,9 +269,17 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
             out.knn_d1 = c->d_knn1.as<int32_t>();
             out.knn_d2 = c->d_knn2.as<int32_t>();
         }
-        launch_sift_finalize(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(),
-                             c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(),
-                             c->d_colpart.as<int32_t>(), rule, out, c->stream);
+        launch_sift_select(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(),
+                           c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, out, c->stream);
+        if (nvitems) {
+            if (c->timing) HIPCHK(c, hipEventRecord(c->ev2, c->stream));
+            launch_sift_verify(c->d_pairs.as<SiftPair>(), c->d_items.as<SiftItem>() + nitems, nvitems, cand, c->stream);
+            if (c->timing) {
+                HIPCHK(c, hipEventRecord(c->ev3, c->stream));
+                c->ev_verify_valid = true;
+            }
+        }
+        launch_sift_confirm(c->d_pairs.as<SiftPair>(), npairs, cand, nvitems ? 1 : 0, out, c->stream);
         if (o.want_pack)
             launch_pack(c->d_pairs.as<SiftPair>(), npairs, c->d_counts.as<int32_t>(),
                         c->d_offsets.as<int64_t>(), c->d_slot0.as<int32_t>(), c->d_slot1.as<int32_t>(),
@@ -322,7 +343,8 @@ extern "C" vsm_ctx* vsm_create(int device)
     vsm_ctx* c = new vsm_ctx();
     c->device = device;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev2)) != hipSuccess || (e = hipEventCreate(&c->ev3)) != hipSuccess) {
         fail(nullptr, VSM_ENODEV, "stream/event creation: %s", hipGetErrorString(e));
         delete c;
         return nullptr;
@@ -339,7 +361,7 @@ extern "C" void vsm_destroy(vsm_ctx* c)
         if (s.frag) (void)hipFree(s.frag);
         if (s.nrm) (void)hipFree(s.nrm);
     }
-    DevBuf* bufs[] = {&c->d_pairs, &c->d_items, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart,
+    DevBuf* bufs[] = {&c->d_pairs, &c->d_items, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart, &c->d_cand,
                       &c->d_slot0, &c->d_slot1, &c->d_slotd, &c->d_counts, &c->d_offsets,
                       &c->d_tight0, &c->d_tight1, &c->d_dense0, &c->d_dense1,
                       &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage};
@@ -349,6 +371,8 @@ extern "C" void vsm_destroy(vsm_ctx* c)
     c->h_small.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev2) (void)hipEventDestroy(c->ev2);
+    if (c->ev3) (void)hipEventDestroy(c->ev3);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -373,6 +397,15 @@ extern "C" int vsm_set_timing(vsm_ctx* c, int on)
     if (!c) return VSM_EINVAL;
     c->timing = on ? 1 : 0;
     return VSM_OK;
+}
+
+extern "C" float vsm_last_verify_ms(vsm_ctx* c)
+{
+    if (!c || !c->ev_verify_valid) return -1.0f;
+    if (hipEventSynchronize(c->ev3) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, c->ev2, c->ev3) != hipSuccess) return -1.0f;
+    return ms;
 }
 
 extern "C" float vsm_last_kernel_ms(vsm_ctx* c)
@@ -664,8 +697,9 @@ extern "C" long long vsm_match_pairs(vsm_ctx* c, const int32_t* pairs, int npair
             const DescSet* A = get_set(c, pairs[2 * (done + take)]);
             const DescSet* B = get_set(c, pairs[2 * (done + take) + 1]);
             if (!A || !B) return fail(c, VSM_EINVAL, "pair %d names an unknown set", done + take);
-            const size_t need = (size_t)(A->n_pad / kStripRows) * B->n_pad * 4;
-            if (take > 0 && (scratch + need > kColpartBudget / 2 || take >= 8192)) break;
+            const size_t chunks = ((size_t)B->n_pad + kChunkCols - 1) / kChunkCols;
+            const size_t need = (chunks * A->n_pad + A->n) * kScratchPerRow;
+            if (take > 0 && (scratch + need > kScratchBudget / 2 || take >= 8192)) break;
             scratch += need;
             ++take;
         }

@@ -15,37 +15,36 @@ namespace vsm {
 //   a k-step as one perfectly coalesced 16-byte-per-lane load, and the 16 bytes are
 //   exactly that lane's operand of v_mfma_i32_32x32x32_i8.  Bytes are stored as
 //   int8 = u8 - 128 (u8 ^ 0x80), padding rows as 0.
-//   nrm8[row] = (sum of squared int8 values) << 8, padding rows kNormPad.
+//   nrm8c[row] = ((sum of squared int8 values) << 8) | (row & 255); padding rows carry
+//   kNormPad in the upper 24 bits.
 // Squared L2 of two u8 descriptors = nrm(a) + nrm(b) - 2*dot(int8 a, int8 b), exact in
 // int32 (< 2^23).
 constexpr int kDescDim = 128;
 constexpr int kRowPad = 256;
 constexpr int kTileBytes = 4096;      // 32 rows * 128 bytes
-constexpr int kStripRows = 256;       // query rows per workgroup (8 waves * 32)
-constexpr int kStepCols = 128;        // train columns per main-loop step
-constexpr int kStepsPerChunk = 64;    // 8-bit step/column-block index: 64 steps * 4 blocks
-constexpr int kChunkCols = kStepCols * kStepsPerChunk;  // 8192
+constexpr int kStripRows = 256;       // persistent rows per workgroup (8 waves * 32)
+constexpr int kStepRows = 128;        // streamed rows per main-loop step
+constexpr int kChunkCols = 8192;      // streamed rows per work item of the query-side pass
 constexpr int32_t kNormPad = 0x7FFFFF00;
 constexpr int32_t kDistPad = 0x7FFFFF;  // (kNormPad >> 8): "no such neighbour"
 
 struct SiftPair {
-    const int8_t* fragA;
+    const int8_t* fragA;     // image 0 (queries)
     const int32_t* nrmA;
-    const int8_t* fragB;
+    const int8_t* fragB;     // image 1 (train)
     const int32_t* nrmB;
     int32_t nA, nB;          // real row counts
     int32_t nA_pad, nB_pad;  // padded to kRowPad
     int32_t nstrips, nchunks;
     int64_t row_off;   // into the per-(chunk,row) partial arrays: nchunks * nA_pad entries
-    int64_t col_off;   // into the per-(strip,col) partial array: nstrips * nB_pad entries
-    int64_t out0_off;  // into per-query-row outputs (nA entries)
+    int64_t out0_off;  // into per-query-row arrays (nA entries): candidates, outputs
     int64_t out1_off;  // into per-train-row outputs (nB entries)
 };
 
 struct SiftItem {
     int32_t pair;
-    int16_t strip;
-    int16_t chunk;
+    int16_t strip;   // query pass: 256-row strip of image 0; verify pass: block of 256 candidates
+    int16_t chunk;   // query pass: 8192-row chunk of image 1
 };
 
 struct MatchRule {
@@ -54,29 +53,45 @@ struct MatchRule {
     int32_t mutual;
 };
 
+// candidates = rows that passed the distance/ratio tests, compact per pair at out0_off
+struct SiftCandidates {
+    int32_t* i0;
+    int32_t* j1;
+    int32_t* d1;
+    int32_t* count;   // [npairs]
+    int32_t* vrow;    // nearest image-0 row of column j1 (filled by the verify pass)
+};
+
 struct SiftOutputs {
     // compacted matches, per pair at out0_off (capacity nA)
     int32_t* slot_i0;
     int32_t* slot_i1;
-    int32_t* slot_d;
+    int32_t* slot_d;   // optional
     int32_t* counts;   // [npairs]
     // optional dense forms
     int32_t* dense0;   // at out0_off, nA entries
-    int32_t* dense1;   // at out1_off, nB entries (pre-filled with -1 by the kernel)
+    int32_t* dense1;   // at out1_off, nB entries
     // optional raw 2-NN
     int32_t* knn_j1;
     int32_t* knn_d1;
     int32_t* knn_d2;
 };
 
-void launch_sift_transform(const uint8_t* des, int n, int n_pad, int8_t* frag, int32_t* nrm8,
+void launch_sift_transform(const uint8_t* des, int n, int n_pad, int8_t* frag, int32_t* nrm8c,
                            hipStream_t s);
-void launch_sift_knn(const SiftPair* pairs, const SiftItem* items, int nitems,
-                     int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, int32_t* colpart,
-                     hipStream_t s);
-void launch_sift_finalize(const SiftPair* pairs, int npairs,
-                          const int32_t* rr_d1, const int32_t* rr_j1, const int32_t* rr_d2,
-                          const int32_t* colpart, MatchRule rule, SiftOutputs out, hipStream_t s);
+// query-side pass: per (chunk, query row) best train row, its distance, runner-up distance
+void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
+                       int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, hipStream_t s);
+// chunk merge + distance/ratio tests -> candidate lists (+ raw 2-NN outputs)
+void launch_sift_select(const SiftPair* pairs, int npairs, const int32_t* rr_d1, const int32_t* rr_j1,
+                        const int32_t* rr_d2, MatchRule rule, SiftCandidates cand, SiftOutputs out,
+                        hipStream_t s);
+// mutual check: nearest image-0 row of every candidate's train row
+void launch_sift_verify(const SiftPair* pairs, const SiftItem* vitems, int nvitems,
+                        SiftCandidates cand, hipStream_t s);
+// keeps the confirmed candidates, writes compact and dense outputs
+void launch_sift_confirm(const SiftPair* pairs, int npairs, SiftCandidates cand, int mutual,
+                         SiftOutputs out, hipStream_t s);
 // counts[npairs] -> offsets[npairs+1] (exclusive scan), then slots -> tight arrays
 void launch_pack(const SiftPair* pairs, int npairs, const int32_t* counts, int64_t* offsets,
                  const int32_t* slot_i0, const int32_t* slot_i1,
