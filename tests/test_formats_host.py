@@ -1,0 +1,212 @@
+"""Host-side product code (file formats, pair lists, C-ABI surface) — no GPU needed.
+
+The product's writers/readers are checked against the reference-generated fixtures and,
+byte for byte, against the oracle's independent restatement."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+import visual_slam_amd as vsm
+from visual_slam_amd import _binding as B
+from visual_slam_amd import host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+# ---- C ABI surface ----------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "vsm.h")).read()
+    declared = set(re.findall(r"\b(vsm_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    lib = C.CDLL(vsm.lib_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libvsm.so does not export %s" % name
+    assert declared == set(B.SIGNATURES), "binding table and header disagree: %s" % (declared ^ set(B.SIGNATURES))
+
+
+def test_create_fails_loudly_without_device():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(vsm.VsmError) as e:
+        vsm.Matcher(0)
+    assert "HIP device" in str(e.value) or "hip" in str(e.value).lower()
+
+
+def test_merge_top2_host():
+    rng = np.random.default_rng(1)
+    ns, nq = 4, 50
+    k1 = rng.random((ns, nq)).astype(np.float32)
+    k2 = k1 + rng.random((ns, nq)).astype(np.float32)
+    i1 = rng.integers(0, 100, (ns, nq)).astype(np.int32)
+    i2 = rng.integers(0, 100, (ns, nq)).astype(np.int32)
+    k1[0, 5] = k1[2, 5] = -1.0   # tie between slices at the top: the lower global index wins
+    base = np.array([0, 100, 200, 300, 400], np.int64)
+    ok1, ok2, oi1, oi2 = B.merge_top2_f32(k1, k2, i1, i2, base, vsm.METRIC_L2)
+    gi1 = i1 + base[:ns, None].astype(np.int32)
+    gi2 = i2 + base[:ns, None].astype(np.int32)
+    e1, e2, ei1, ei2 = orc.merge_top2_f32(k1, k2, gi1, gi2, orc.METRIC_L2)
+    np.testing.assert_array_equal(ok1, e1)
+    np.testing.assert_array_equal(ok2, e2)
+    np.testing.assert_array_equal(oi1, ei1)
+    np.testing.assert_array_equal(oi2, ei2)
+    assert oi1[5] == gi1[0, 5]
+
+
+# ---- .sift ----------------------------------------------------------------------------------------
+def test_sift_roundtrip_and_bytes(tmp_path):
+    rng = np.random.default_rng(2)
+    for n in (1, 3, 777):
+        loc = rng.random((n, 5)).astype(np.float32) * 100
+        des = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+        p, q = str(tmp_path / ("p%d.sift" % n)), str(tmp_path / ("o%d.sift" % n))
+        host.write_sift(p, loc, des)
+        orc.sift_write(q, loc, des)
+        assert open(p, "rb").read() == open(q, "rb").read()
+        assert os.path.getsize(p) == 20 + n * 20 + n * 128 + 4
+        l2, d2 = host.read_sift(p)
+        np.testing.assert_array_equal(l2, loc)
+        np.testing.assert_array_equal(d2, des)
+        l3, d3 = host.read_sift(p, nmax=max(1, n // 2))
+        np.testing.assert_array_equal(d3, des[:max(1, n // 2)])
+        np.testing.assert_array_equal(l3, loc[:max(1, n // 2)])
+
+
+def test_sift_reader_rejects_bad_files(tmp_path):
+    p = str(tmp_path / "bad.sift")
+    loc = np.zeros((2, 5), np.float32)
+    des = np.ones((2, 128), np.uint8)
+    host.write_sift(p, loc, des)
+    raw = bytearray(open(p, "rb").read())
+    for off, val in ((0, b"XIFT"), (4, b"V9.0"), (16, np.int32(64).tobytes()), (8, np.int32(0).tobytes())):
+        bad = bytearray(raw)
+        bad[off:off + 4] = val
+        open(p, "wb").write(bad)
+        with pytest.raises(vsm.VsmError):
+            host.read_sift(p)
+    with pytest.raises(vsm.VsmError):
+        host.read_sift(str(tmp_path / "missing.sift"))
+    # the reference's txt->sift path writes descriptors of all ones (FeaturePoints.cpp:358-367)
+    open(p, "wb").write(raw)
+    _, d = host.read_sift(p)
+    assert (d == 1).all()
+
+
+# ---- match txt / keypoint txt / pair list -------------------------------------------------------
+def test_matchtxt_matches_reference(tmp_path):
+    z = np.load(os.path.join(G, "matching_ref_inputs.npz"))
+    ref = open(os.path.join(G, "matching_ref.txt")).read()
+    p = str(tmp_path / "matching.txt")
+    assert host.save_matching_sfm(p, z["m_a"], "0.jpg", "1.jpg") == 3
+    assert host.save_matching_sfm(p, z["m_b"], "0.jpg", "2.jpg") == 4
+    assert host.save_matching_sfm(p, z["m_c"], "1.jpg", "2.jpg") == 0
+    assert open(p).read() == ref
+    # list form
+    q = str(tmp_path / "matching2.txt")
+    for m, a, b in ((z["m_a"], "0.jpg", "1.jpg"), (z["m_b"], "0.jpg", "2.jpg"), (z["m_c"], "1.jpg", "2.jpg")):
+        i0 = np.nonzero(m != -1)[0]
+        host.save_matching_list(q, i0, m[i0], len(m), a, b)
+    assert open(q).read() == ref
+    # python mirror of the string builder
+    l0, l1, n = host.get_list_matching_pairs(z["m_a"])
+    assert (l0, l1, n) == ("1 4 11", "7 0 3", 3)
+    l0, l1, n = host.get_list_matching_pairs(z["m_b"])
+    assert (l0, l1, n) == ("0 2 3 7 ", "5 8 1 2 ", 4)
+
+
+def test_feature_txt_matches_reference(tmp_path):
+    kp = np.load(os.path.join(G, "feature_ref_inputs.npy"))
+    p = str(tmp_path / "0.txt")
+    host.save_feature_locations(kp, p)
+    assert open(p).read() == open(os.path.join(G, "feature_ref.txt")).read()
+    back = host.read_feature_locations(p)
+    np.testing.assert_array_equal(back, np.trunc(kp))
+
+
+def test_pair_lists():
+    names = [str(i) + ".jpg" for i in range(20)]
+    ref = [ln.split() for ln in open(os.path.join(G, "pairs_ref.txt")).read().splitlines()]
+    assert host.generate_imagePairs(names) == ref
+    ex = host.generate_exhaustive_pairs(7)
+    assert len(ex) == 21 and ex[0].tolist() == [0, 1] and ex[-1].tolist() == [5, 6]
+    assert len(host.generate_exhaustive_pairs(1000)) == 499500
+
+
+# ---- .mat ---------------------------------------------------------------------------------------------
+def test_mat_bytes_match_oracle(tmp_path):
+    """A sequence of writes, including re-writes of an existing partner, gives the same bytes from
+    the product writer and from the oracle's restatement, and each reads the other's files."""
+    rng = np.random.default_rng(3)
+    d1, d2 = tmp_path / "p", tmp_path / "o"
+    d1.mkdir()
+    d2.mkdir()
+    fc = [50, 60, 70, 80]
+    seq = [(0, 1, 5), (0, 2, 9), (1, 2, 0), (0, 3, 20), (0, 3, 12), (2, 3, 33)]
+    for a, b, nm in seq:
+        ia = np.sort(rng.choice(fc[a], nm, replace=False)).astype(np.int32)
+        ib = rng.integers(0, fc[b], nm).astype(np.int32)
+        host.write_pmatch(str(d1 / str(a)), str(d1 / str(b)), fc[a], fc[b], ia, ib)
+        assert orc.mat_write_pmatch(str(d2 / str(a)), str(d2 / str(b)), fc[a], fc[b], ia, ib) == 0
+        last = (a, b, ia, ib)
+    for i in range(4):
+        assert open(d1 / ("%d.mat" % i), "rb").read() == open(d2 / ("%d.mat" % i), "rb").read()
+    a, b, ia, ib = last
+    ga, gb = host.get_pmatch(str(d2 / str(a)), str(d2 / str(b)), fc[b])      # product reads oracle's file
+    np.testing.assert_array_equal(ga, ia)
+    np.testing.assert_array_equal(gb, ib)
+    oa, ob = orc.mat_get_pmatch(str(d1 / str(b)), str(d1 / str(a)), fc[a])     # oracle reads product's file
+    np.testing.assert_array_equal(oa, ib)
+    np.testing.assert_array_equal(ob, ia)
+    assert host.get_match_count(str(d1 / str(a)), str(d1 / str(b))) == (33, 0)
+    assert host.get_match_count(str(d1 / "0"), str(d1 / "9")) is None
+    assert len(host.get_pmatch(str(d1 / str(a)), str(d1 / str(b)), fc[b] + 1)[0]) == 0
+
+
+def test_mat_first_file_size(tmp_path):
+    a, b = str(tmp_path / "0"), str(tmp_path / "1")
+    host.write_pmatch(a, b, 10, 12, [1, 4, 7], [0, 5, 9])
+    assert os.path.getsize(a + ".mat") == 5912 and os.path.getsize(b + ".mat") == 5912
+
+
+def test_mat_directory_growth(tmp_path):
+    """More partners than the directory was reserved for: the directory doubles and every record
+    stays readable (the reference's AddImageMatch regrow path, MatchFile.cpp:494-560)."""
+    rng = np.random.default_rng(4)
+    n = 300
+    truth = {}
+    hub = str(tmp_path / "hub")
+    for k in range(n):
+        nm = int(rng.integers(1, 30))
+        ia = np.sort(rng.choice(100, nm, replace=False)).astype(np.int32)
+        ib = rng.integers(0, 40 + k, nm).astype(np.int32)
+        host.write_pmatch(hub, str(tmp_path / ("img%03d" % k)), 100, 40 + k, ia, ib)
+        truth[k] = (ia, ib)
+    for k in range(n):
+        ga, gb = host.get_pmatch(hub, str(tmp_path / ("img%03d" % k)), 40 + k)
+        np.testing.assert_array_equal(ga, truth[k][0])
+        np.testing.assert_array_equal(gb, truth[k][1])
+        # the oracle's reader walks the same directory
+        oa, ob = orc.mat_get_pmatch(hub, str(tmp_path / ("img%03d" % k)), 40 + k)
+        np.testing.assert_array_equal(oa, truth[k][0])
+        np.testing.assert_array_equal(ob, truth[k][1])
+    # with a reservation the directory never has to grow
+    hub2 = str(tmp_path / "hub2")
+    for k in range(n):
+        host.write_pmatch(hub2, str(tmp_path / ("jmg%03d" % k)), 100, 40 + k, truth[k][0], truth[k][1], reservation=n)
+    assert np.frombuffer(open(hub2 + ".mat", "rb").read(20), np.int32)[3] == n * 284
+    ga, gb = host.get_pmatch(hub2, str(tmp_path / "jmg299"), 40 + 299)
+    np.testing.assert_array_equal(ga, truth[299][0])
+
+
+def test_ratio_fraction():
+    assert B.ratio_to_fraction(0.8) == (4, 5)
+    assert B.ratio_to_fraction(0.75) == (3, 4)
+    assert B.ratio_to_fraction(None) == (0, 1)
+    n, d = B.ratio_to_fraction(0.7)
+    assert (n, d) == (7, 10)

@@ -1,0 +1,159 @@
+"""GPU parity: float descriptors (SuperPoint-256 style) through the C ABI against the CPU oracle
+and the reference-generated fixtures.
+
+Bar: indices bit-exact; scores/distances bit-exact against the oracle's k-ascending fmaf chain
+(the f32-input MFMA is that chain), and within 1e-5 relative (2e-6 absolute floor, for distances
+of near-duplicates where |a|^2 + |b|^2 - 2ab cancels) of a float64 computation."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+import visual_slam_amd as vsm
+from visual_slam_amd import _binding as B
+from visual_slam_amd import host, synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _knn_check(matcher, a, b, metric):
+    s0, s1 = matcher.upload_f32(a), matcher.upload_f32(b)
+    try:
+        gi1, gi2, gk1, gk2 = matcher.knn2(s0, s1, metric, want_idx2=True)
+        oi, ok1, ok2 = orc.knn2_f32(a, b, metric)
+        np.testing.assert_array_equal(gi1, oi)
+        np.testing.assert_array_equal(gk1, ok1)
+        np.testing.assert_array_equal(gk2, ok2)
+        if len(b) >= 2:
+            assert (gi2 >= 0).all() and (gi2 != gi1).all()
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)
+
+
+@pytest.mark.parametrize("n0,n1,dim", [(1, 1, 256), (3, 2, 256), (200, 300, 256), (257, 1025, 256),
+                                       (1024, 1024, 256), (100, 90, 128), (70, 50, 64), (40, 33, 100), (9, 300, 7)])
+@pytest.mark.parametrize("metric", [vsm.METRIC_DOT, vsm.METRIC_L2])
+def test_knn2_matches_oracle(matcher, n0, n1, dim, metric):
+    a, b = synth.superpoint_pair(n0, n1, dim, seed=100 + n0 + n1 + dim)
+    _knn_check(matcher, a, b, metric)
+
+
+def test_knn2_non_unit_vectors_l2(matcher):
+    rng = np.random.default_rng(5)
+    a = rng.random((300, 256), dtype=np.float32) * 3
+    b = rng.random((500, 256), dtype=np.float32) * 3
+    _knn_check(matcher, a, b, vsm.METRIC_L2)
+    D = ((a[:, None, :].astype(np.float64) - b[None].astype(np.float64)) ** 2).sum(-1)
+    s0, s1 = matcher.upload_f32(a), matcher.upload_f32(b)
+    gi, gd1, gd2 = matcher.knn2(s0, s1, vsm.METRIC_L2)
+    np.testing.assert_array_equal(gi, D.argmin(1))
+    np.testing.assert_allclose(gd1, D.min(1), rtol=1e-5, atol=2e-6 * 256)
+    matcher.release(s0)
+    matcher.release(s1)
+
+
+def test_ties_first_index(matcher):
+    rng = np.random.default_rng(6)
+    base = synth.unit_f32(30, 256, rng)
+    a = np.concatenate([base, base[:10]])
+    b = np.concatenate([base[::-1], base[:20], base])
+    for metric in (vsm.METRIC_DOT, vsm.METRIC_L2):
+        _knn_check(matcher, a, b, metric)
+
+
+def test_layout_dim_major(matcher):
+    a, b = synth.superpoint_pair(150, 170, 256, seed=7)
+    s0 = matcher.upload_f32(np.ascontiguousarray(a.T), vsm.LAYOUT_DIM_MAJOR)
+    s1 = matcher.upload_f32(np.ascontiguousarray(b.T), vsm.LAYOUT_DIM_MAJOR)
+    gi, gk1, gk2 = matcher.knn2(s0, s1, vsm.METRIC_DOT)
+    oi, ok1, ok2 = orc.knn2_f32(a, b, orc.METRIC_DOT)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gk1, ok1)
+    matcher.release(s0)
+    matcher.release(s1)
+
+
+@pytest.mark.parametrize("metric,ratio", [(vsm.METRIC_DOT, None), (vsm.METRIC_L2, 0.8), (vsm.METRIC_L2, None)])
+def test_match_dense_matches_oracle(matcher, metric, ratio):
+    a, b = synth.superpoint_pair(600, 700, 256, seed=8)
+    s0, s1 = matcher.upload_f32(a), matcher.upload_f32(b)
+    fr = (4, 5) if ratio else None
+    for mutual in (True, False):
+        g0, g1 = matcher.match_pair_dense(s0, s1, ratio=ratio, mutual=mutual, metric=metric, min_score=0.5)
+        o0, o1, _, _ = orc.match_dense_f32(a, b, metric, orc.params(fr, mutual, min_score=0.5))
+        np.testing.assert_array_equal(g0, o0)
+        np.testing.assert_array_equal(g1, o1)
+        i0, i1, sc = matcher.match_pair(s0, s1, ratio=ratio, mutual=mutual, metric=metric, min_score=0.5,
+                                        return_dist=True)
+        np.testing.assert_array_equal(i0, np.nonzero(o0 >= 0)[0])
+        np.testing.assert_array_equal(i1, o0[o0 >= 0])
+    assert (o0 >= 0).sum() > 50
+    matcher.release(s0)
+    matcher.release(s1)
+
+
+def test_mutual_block_fixture(matcher):
+    """Same outputs as the reference's mutual-argmax block run on the same descriptors."""
+    z = np.load(os.path.join(G, "mutual_block.npz"))
+    for tag in ("a", "b"):
+        out = host.mutual_nn_match(matcher, z["desc0_" + tag], z["desc1_" + tag], match_threshold=0.2)
+        np.testing.assert_array_equal(out["matches0"], z["matches0_" + tag])
+        np.testing.assert_array_equal(out["matches1"], z["matches1_" + tag])
+        np.testing.assert_allclose(out["matching_scores0"], z["mscores0_" + tag], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(out["matching_scores1"], z["mscores1_" + tag], rtol=1e-5, atol=1e-6)
+        # the library's own dense matcher with the threshold moved onto the raw dot product
+        s0 = matcher.upload_f32(z["desc0_" + tag], vsm.LAYOUT_DIM_MAJOR)
+        s1 = matcher.upload_f32(z["desc1_" + tag], vsm.LAYOUT_DIM_MAJOR)
+        m0, m1 = matcher.match_pair_dense(s0, s1, ratio=None, mutual=True, metric=vsm.METRIC_DOT,
+                                          min_score=np.float32(16.0 * math.log(0.2)))
+        np.testing.assert_array_equal(m0, z["matches0_" + tag])
+        np.testing.assert_array_equal(m1, z["matches1_" + tag])
+        matcher.release(s0)
+        matcher.release(s1)
+
+
+def test_nearest_embed_fixture(matcher):
+    z = np.load(os.path.join(G, "nearest_embed.npz"))
+    for sfx in ("", "2"):
+        res, am = host.nearest_embed(matcher, z["x" + sfx], z["emb" + sfx])
+        np.testing.assert_array_equal(am, z["argmin" + sfx])
+        np.testing.assert_array_equal(res, z["result" + sfx])
+        ores, oam = orc.nearest_embed_f32(z["x" + sfx], z["emb" + sfx])
+        np.testing.assert_array_equal(am, oam)
+
+
+def test_database_slices_merge(matcher):
+    """Database cut into contiguous slices, per-slice 2-NN merged = 2-NN over the whole database."""
+    rng = np.random.default_rng(9)
+    q = synth.unit_f32(300, 256, rng)
+    db = synth.unit_f32(2000, 256, rng)
+    db[1500] = db[20]          # duplicate rows in different slices
+    db[700] = q[5]
+    db[1900] = q[5]
+    cuts = [0, 512, 1100, 1100 + 333, 2000]
+    sq = matcher.upload_f32(q)
+    for metric in (vsm.METRIC_L2, vsm.METRIC_DOT):
+        k1s, k2s, i1s, i2s = [], [], [], []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            sd = matcher.upload_f32(db[lo:hi])
+            i1, i2, k1, k2 = matcher.knn2(sq, sd, metric, want_idx2=True)
+            k1s.append(k1.copy()); k2s.append(k2.copy()); i1s.append(i1.copy()); i2s.append(i2.copy())
+            matcher.release(sd)
+        ok1, ok2, oi1, oi2 = B.merge_top2_f32(np.stack(k1s), np.stack(k2s), np.stack(i1s), np.stack(i2s),
+                                              np.asarray(cuts, np.int64), metric)
+        sd = matcher.upload_f32(db)
+        wi1, wi2, wk1, wk2 = matcher.knn2(sq, sd, metric, want_idx2=True)
+        matcher.release(sd)
+        np.testing.assert_array_equal(oi1, wi1)
+        np.testing.assert_array_equal(oi2, wi2)
+        np.testing.assert_array_equal(ok1, wk1)
+        np.testing.assert_array_equal(ok2, wk2)
+        oi, o1, o2 = orc.knn2_f32(q, db, metric)
+        np.testing.assert_array_equal(oi1, oi)
+        np.testing.assert_array_equal(ok1, o1)
+        np.testing.assert_array_equal(ok2, o2)
+    matcher.release(sq)

@@ -1,0 +1,83 @@
+"""Multi-process paths on CPU (gloo, world_size 2): the pair-list sharding bench.py uses, and the
+sliced-database 2-NN merge (per-rank local 2-NN -> all_gather -> host merge).  The per-rank local
+search is done by the CPU oracle here (no GPU in this tier); the exchange and the merge are the
+product code paths."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import oracle_lib as orc
+    import visual_slam_amd as vsm
+    from visual_slam_amd import _binding as B
+    from visual_slam_amd import synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    # ---- pair-list sharding: contiguous shards, every pair exactly once -------------------
+    pairs = vsm.generate_exhaustive_pairs(23)
+    per = len(pairs) // world
+    shard = pairs[rank * per:(rank + 1) * per]
+    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([len(shard)], dtype=torch.int64))
+    assert sum(int(c) for c in counts) == per * world
+    firsts = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(firsts, torch.tensor(shard[0].tolist(), dtype=torch.int64))
+    assert firsts[rank].tolist() == pairs[rank * per].tolist()
+
+    # ---- sliced database: local 2-NN per rank, all_gather, merge -----------------------------
+    rng = np.random.default_rng(42)          # same stream on every rank
+    q = synth.unit_f32(64, 256, rng)
+    db = synth.unit_f32(1000, 256, rng)
+    db[900] = db[10]                         # duplicate across slices: lower global index must win
+    per_db = (len(db) + world - 1) // world
+    lo, hi = rank * per_db, min(len(db), (rank + 1) * per_db)
+    base = np.asarray([min(len(db), r * per_db) for r in range(world + 1)], np.int64)
+    for metric in (vsm.METRIC_L2, vsm.METRIC_DOT):
+        # local top-2 with indices: nearest, then nearest with the winner removed
+        i1, k1, k2 = orc.knn2_f32(q, db[lo:hi], metric)
+        i2 = np.empty_like(i1)
+        for r in range(len(q)):
+            sl = db[lo:hi].copy()
+            sl[i1[r]] = -q[r] * 10 if metric == vsm.METRIC_DOT else q[r] + 100.0
+            i2[r] = orc.knn2_f32(q[r:r + 1], sl, metric)[0][0]
+        pack = torch.from_numpy(np.stack([k1.view(np.int32), k2.view(np.int32), i1, i2]))
+        allp = [torch.empty_like(pack) for _ in range(world)]
+        dist.all_gather(allp, pack)
+        allp = torch.stack(allp).numpy()
+        ok1, ok2, oi1, oi2 = B.merge_top2_f32(allp[:, 0].view(np.float32), allp[:, 1].view(np.float32),
+                                              allp[:, 2], allp[:, 3], base, metric)
+        wi, wk1, wk2 = orc.knn2_f32(q, db, metric)
+        np.testing.assert_array_equal(oi1, wi)
+        np.testing.assert_array_equal(ok1, wk1)
+        np.testing.assert_array_equal(ok2, wk2)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
+
+
+def test_world_size_two(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
