@@ -67,8 +67,8 @@ void launch_sift_transform(const uint8_t* des, int n, int n_pad, int8_t* frag, i
 // streaming MFMA passes
 // ---------------------------------------------------------------------------------
 // Workgroup = 8 waves.  Wave w keeps the MFMA operand of 32 "persistent" rows in registers;
-// the other set streams through LDS in 128-row steps (16 KiB, already in operand order in
-// HBM, copied by LDS-DMA, double buffered), and every wave multiplies its 32 rows by all four
+// the other set streams through LDS in 256-row steps (32 KiB, already in operand order in
+// HBM, copied by LDS-DMA, double buffered), and every wave multiplies its 32 rows by all eight
 // 32-row tiles of the step.
 //
 // The persistent rows sit on the accumulator's LANE axis (they are the B operand): lane l owns
@@ -84,8 +84,11 @@ void launch_sift_transform(const uint8_t* des, int n, int n_pad, int8_t* frag, i
 // nrm * 256 + (row & 255)).  The packed minimum is exact inside a group of 256 streamed rows
 // and resolves ties to the lower row; after every group it is folded into an unpacked running
 // best with a strict compare, which keeps the lower row across groups as well.
-constexpr int kLdsTile = 16384;
-constexpr int kLdsStream = 2 * kLdsTile + 2 * 512;
+constexpr int kTilesPerStep = kStepRows / 32;            // 8 tiles of 32 streamed rows
+constexpr int kLdsTile = kStepRows * kDescDim;           // 32 KiB of descriptors per step
+constexpr int kLdsNorm = kStepRows * 4;                  // 1 KiB of packed norms per step
+constexpr int kLdsStream = 2 * kLdsTile + 2 * kLdsNorm;  // double buffered
+static_assert(kStepRows == 256, "a step is exactly one 256-row index group");
 
 __device__ __forceinline__ int min3i(int a, int b, int c)
 {
@@ -117,14 +120,17 @@ __device__ __forceinline__ int xcd_contiguous_item(int bid, int nb)
     return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
 }
 
-// one step's LDS-DMA: 16 KiB of operand-order descriptors + 128 packed norms
+// one step's LDS-DMA: 32 KiB of operand-order descriptors (4 KiB per wave) + 256 packed norms.
+// frag_src / nrm_src already include this wave's and lane's offsets.
 __device__ __forceinline__ void stage_step(char* smem, int buf, const int8_t* frag_src, const int32_t* nrm_src,
                                            int wave)
 {
-    char* dst = smem + buf * kLdsTile + wave * 2048;
+    char* dst = smem + buf * kLdsTile + wave * 4096;
     dma16(frag_src, dst);
     dma16(frag_src + 1024, dst + 1024);
-    if (wave < 2) dma4(nrm_src, smem + 2 * kLdsTile + buf * 512 + wave * 256);
+    dma16(frag_src + 2048, dst + 2048);
+    dma16(frag_src + 3072, dst + 3072);
+    if (wave < 4) dma4(nrm_src, smem + 2 * kLdsTile + buf * kLdsNorm + wave * 256);
 }
 
 // per-tile accumulators of one wave: streamed tile (A operand) x persistent rows (B operand)
@@ -173,7 +179,7 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
 
     const int c0 = it.chunk * kChunkCols;
     const int ncols = min(kChunkCols, pw.nB_pad - c0);
-    const int nsteps = ncols / kStepRows;  // even: sets are padded to 256 rows
+    const int nsteps = ncols / kStepRows;  // sets are padded to 256 rows
 
     // persistent operand: this wave's 32 query rows
     const int qtile = it.strip * (kStripRows / 32) + wave;
@@ -184,10 +190,9 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
         for (int s = 0; s < 4; ++s) pf[s] = *reinterpret_cast<const v4i*>(src + s * 1024);
     }
 
-    const int8_t* Bsrc = pw.fragB + (size_t)(c0 >> 5) * kTileBytes + wave * 2048 + lane * 16;
-    const int32_t* Nsrc = pw.nrmB + c0 + (wave & 1) * 64 + lane;
+    const int8_t* Bsrc = pw.fragB + (size_t)(c0 >> 5) * kTileBytes + wave * 4096 + lane * 16;
+    const int32_t* Nsrc = pw.nrmB + c0 + (wave & 3) * 64 + lane;
 
-    int k1 = INT32_MAX, k2 = INT32_MAX;            // packed, current 256-column group
     int bestd = kDistPad, bestcol = INT32_MAX, second = kDistPad;  // unpacked running result
 
     stage_step(smem, 0, Bsrc, Nsrc, wave);
@@ -198,11 +203,15 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
         if (st + 1 < nsteps)
             stage_step(smem, cur ^ 1, Bsrc + (size_t)(st + 1) * kLdsTile, Nsrc + (st + 1) * kStepRows, wave);
         const char* Bt = smem + cur * kLdsTile + lane * 16;
-        const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * 512);
+        const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm);
 
+        int k1 = INT32_MAX, k2 = INT32_MAX;  // packed two smallest of this 256-row group
+        // software pipeline: the MFMAs of tile t + 1 are issued before the epilogue of tile t
+        v16i acc = tile_dot(Bt, pf);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const v16i acc = tile_dot(Bt + t * 4096, pf);
+        for (int t = 0; t < kTilesPerStep; ++t) {
+            v16i nxt = acc;
+            if (t + 1 < kTilesPerStep) nxt = tile_dot(Bt + (t + 1) * 4096, pf);
             int c[16];
             tile_consts(nl + t * 32, half, c);
             int u[8];
@@ -217,11 +226,13 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
             k2 = min3i(k2, u[2], u[3]);
             k2 = min3i(k2, u[4], u[5]);
             k2 = min3i(k2, u[6], u[7]);
+            acc = nxt;
         }
-        if (st & 1) {
-            // fold the finished 256-column group into the running result
+        {
+            // fold the finished 256-row group into the running result (strict compare: on equal
+            // distances the earlier group, i.e. the lower row, stays)
             const int d = k1 >> 8;
-            const int col = c0 + (st - 1) * kStepRows + (k1 & 255);
+            const int col = c0 + st * kStepRows + (k1 & 255);
             if (d < bestd) {
                 second = min(second, bestd);
                 bestd = d;
@@ -230,8 +241,6 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
                 second = min(second, d);
             }
             second = min(second, k2 >> 8);
-            k1 = INT32_MAX;
-            k2 = INT32_MAX;
         }
         __syncthreads();
     }
@@ -262,6 +271,12 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
 void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
                        int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, hipStream_t s)
 {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sift_query_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsStream);
+        attr_set = true;
+    }
     hipLaunchKernelGGL(sift_query_kernel, dim3(nitems), dim3(512), kLdsStream, s,
                        pairs, items, rr_d1, rr_j1, rr_d2, -512);
 }
@@ -297,10 +312,9 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
     }
 
     const int nsteps = pw.nA_pad / kStepRows;
-    const int8_t* Asrc = pw.fragA + wave * 2048 + lane * 16;
-    const int32_t* Nsrc = pw.nrmA + (wave & 1) * 64 + lane;
+    const int8_t* Asrc = pw.fragA + wave * 4096 + lane * 16;
+    const int32_t* Nsrc = pw.nrmA + (wave & 3) * 64 + lane;
 
-    int m = INT32_MAX;
     int bestd = kDistPad, bestrow = INT32_MAX;
 
     stage_step(smem, 0, Asrc, Nsrc, wave);
@@ -311,10 +325,13 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
         if (st + 1 < nsteps)
             stage_step(smem, cur ^ 1, Asrc + (size_t)(st + 1) * kLdsTile, Nsrc + (st + 1) * kStepRows, wave);
         const char* At = smem + cur * kLdsTile + lane * 16;
-        const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * 512);
+        const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm);
+        int m = INT32_MAX;
+        v16i acc = tile_dot(At, pf);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const v16i acc = tile_dot(At + t * 4096, pf);
+        for (int t = 0; t < kTilesPerStep; ++t) {
+            v16i nxt = acc;
+            if (t + 1 < kTilesPerStep) nxt = tile_dot(At + (t + 1) * 4096, pf);
             int c[16];
             tile_consts(nl + t * 32, half, c);
 #pragma unroll
@@ -323,14 +340,14 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
                 const int y1 = __mul24(acc[2 * e + 1], negscale) + c[2 * e + 1];
                 m = min3i(m, y0, y1);
             }
+            acc = nxt;
         }
-        if (st & 1) {
+        {
             const int d = m >> 8;
             if (d < bestd) {
                 bestd = d;
-                bestrow = (st - 1) * kStepRows + (m & 255);
+                bestrow = st * kStepRows + (m & 255);
             }
-            m = INT32_MAX;
         }
         __syncthreads();
     }
@@ -348,6 +365,12 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
 void launch_sift_verify(const SiftPair* pairs, const SiftItem* vitems, int nvitems,
                         SiftCandidates cand, hipStream_t s)
 {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sift_verify_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsStream);
+        attr_set = true;
+    }
     hipLaunchKernelGGL(sift_verify_kernel, dim3(nvitems), dim3(512), kLdsStream, s,
                        pairs, vitems, cand, -512);
 }

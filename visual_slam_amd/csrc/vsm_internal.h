@@ -23,7 +23,7 @@ constexpr int kDescDim = 128;
 constexpr int kRowPad = 256;
 constexpr int kTileBytes = 4096;      // 32 rows * 128 bytes
 constexpr int kStripRows = 256;       // persistent rows per workgroup (8 waves * 32)
-constexpr int kStepRows = 128;        // streamed rows per main-loop step
+constexpr int kStepRows = 256;        // streamed rows per main-loop step
 constexpr int kChunkCols = 8192;      // streamed rows per work item of the query-side pass
 constexpr int32_t kNormPad = 0x7FFFFF00;
 constexpr int32_t kDistPad = 0x7FFFFF;  // (kNormPad >> 8): "no such neighbour"
