@@ -162,7 +162,11 @@ __device__ __forceinline__ void tile_consts(const int* nl_tile, int half, int (&
 }
 
 // ---- 1. query pass ------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2)
+// Each wave owns kQueryRB blocks of 32 query rows; they share every streamed operand and norm
+// read, which halves the LDS traffic per MFMA.
+constexpr int kQueryRB = kStripRows / 256;
+
+__global__ __launch_bounds__(512, 4)
 void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ items,
                        int32_t* __restrict__ rr_d1, int32_t* __restrict__ rr_j1,
                        int32_t* __restrict__ rr_d2, int negscale)
@@ -179,21 +183,25 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
 
     const int c0 = it.chunk * kChunkCols;
     const int ncols = min(kChunkCols, pw.nB_pad - c0);
-    const int nsteps = ncols / kStepRows;  // sets are padded to 256 rows
+    const int nsteps = ncols / kStepRows;  // sets are padded to whole steps
 
-    // persistent operand: this wave's 32 query rows
-    const int qtile = it.strip * (kStripRows / 32) + wave;
-    v4i pf[4];
-    {
-        const int8_t* src = pw.fragA + (size_t)qtile * kTileBytes + lane * 16;
+    // persistent operand: this wave's query rows
+    const int qtile = (it.strip * (kStripRows / 32)) + wave * kQueryRB;
+    v4i pf[kQueryRB][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) pf[s] = *reinterpret_cast<const v4i*>(src + s * 1024);
+    for (int rb = 0; rb < kQueryRB; ++rb) {
+        const int8_t* src = pw.fragA + (size_t)(qtile + rb) * kTileBytes + lane * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pf[rb][s] = *reinterpret_cast<const v4i*>(src + s * 1024);
     }
 
     const int8_t* Bsrc = pw.fragB + (size_t)(c0 >> 5) * kTileBytes + wave * 4096 + lane * 16;
     const int32_t* Nsrc = pw.nrmB + c0 + (wave & 3) * 64 + lane;
 
-    int bestd = kDistPad, bestcol = INT32_MAX, second = kDistPad;  // unpacked running result
+    // unpacked running result per query row
+    int bestd[kQueryRB], bestcol[kQueryRB], second[kQueryRB];
+#pragma unroll
+    for (int rb = 0; rb < kQueryRB; ++rb) { bestd[rb] = kDistPad; bestcol[rb] = INT32_MAX; second[rb] = kDistPad; }
 
     stage_step(smem, 0, Bsrc, Nsrc, wave);
     __syncthreads();
@@ -205,66 +213,83 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
         const char* Bt = smem + cur * kLdsTile + lane * 16;
         const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm);
 
-        int k1 = INT32_MAX, k2 = INT32_MAX;  // packed two smallest of this 256-row group
-        // software pipeline: the MFMAs of tile t + 1 are issued before the epilogue of tile t
-        v16i acc = tile_dot(Bt, pf);
+        int k1[kQueryRB], k2[kQueryRB];  // packed two smallest of this 256-row group
+#pragma unroll
+        for (int rb = 0; rb < kQueryRB; ++rb) { k1[rb] = INT32_MAX; k2[rb] = INT32_MAX; }
+
 #pragma unroll
         for (int t = 0; t < kTilesPerStep; ++t) {
-            v16i nxt = acc;
-            if (t + 1 < kTilesPerStep) nxt = tile_dot(Bt + (t + 1) * 4096, pf);
+            const char* tile = Bt + t * 4096;
+            const v4i b0 = *reinterpret_cast<const v4i*>(tile);
+            const v4i b1 = *reinterpret_cast<const v4i*>(tile + 1024);
+            const v4i b2 = *reinterpret_cast<const v4i*>(tile + 2048);
+            const v4i b3 = *reinterpret_cast<const v4i*>(tile + 3072);
             int c[16];
             tile_consts(nl + t * 32, half, c);
-            int u[8];
+            v16i acc[kQueryRB];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int x0 = __mul24(acc[2 * e], negscale) + c[2 * e];
-                const int x1 = __mul24(acc[2 * e + 1], negscale) + c[2 * e + 1];
-                u[e] = med3i(k1, x0, x1);   // runner-up of {k1, x0, x1}
-                k1 = min3i(k1, x0, x1);
+            for (int rb = 0; rb < kQueryRB; ++rb) {
+                v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b0, pf[rb][0], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b1, pf[rb][1], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b2, pf[rb][2], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b3, pf[rb][3], z, 0, 0, 0);
+                acc[rb] = z;
             }
-            k2 = min3i(k2, u[0], u[1]);
-            k2 = min3i(k2, u[2], u[3]);
-            k2 = min3i(k2, u[4], u[5]);
-            k2 = min3i(k2, u[6], u[7]);
-            acc = nxt;
+#pragma unroll
+            for (int rb = 0; rb < kQueryRB; ++rb) {
+                int uprev = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int x0 = __mul24(acc[rb][2 * e], negscale) + c[2 * e];
+                    const int x1 = __mul24(acc[rb][2 * e + 1], negscale) + c[2 * e + 1];
+                    const int u = med3i(k1[rb], x0, x1);   // runner-up of {k1, x0, x1}
+                    k1[rb] = min3i(k1[rb], x0, x1);
+                    if (e & 1) k2[rb] = min3i(k2[rb], uprev, u);
+                    uprev = u;
+                }
+            }
         }
-        {
+#pragma unroll
+        for (int rb = 0; rb < kQueryRB; ++rb) {
             // fold the finished 256-row group into the running result (strict compare: on equal
             // distances the earlier group, i.e. the lower row, stays)
-            const int d = k1 >> 8;
-            const int col = c0 + st * kStepRows + (k1 & 255);
-            if (d < bestd) {
-                second = min(second, bestd);
-                bestd = d;
-                bestcol = col;
+            const int d = k1[rb] >> 8;
+            const int col = c0 + st * kStepRows + (k1[rb] & 255);
+            if (d < bestd[rb]) {
+                second[rb] = min(second[rb], bestd[rb]);
+                bestd[rb] = d;
+                bestcol[rb] = col;
             } else {
-                second = min(second, d);
+                second[rb] = min(second[rb], d);
             }
-            second = min(second, k2 >> 8);
+            second[rb] = min(second[rb], k2[rb] >> 8);
         }
         __syncthreads();
     }
 
-    // lanes l and l + 32 saw disjoint columns of the same query row
-    {
-        const int od = __shfl_xor(bestd, 32);
-        const int oc = __shfl_xor(bestcol, 32);
-        const int os = __shfl_xor(second, 32);
-        const bool other_wins = od < bestd || (od == bestd && oc < bestcol);
-        const int loser = other_wins ? bestd : od;
+#pragma unroll
+    for (int rb = 0; rb < kQueryRB; ++rb) {
+        // lanes l and l + 32 saw disjoint columns of the same query row
+        int bd = bestd[rb], bc = bestcol[rb], sc = second[rb];
+        const int od = __shfl_xor(bd, 32);
+        const int oc = __shfl_xor(bc, 32);
+        const int os = __shfl_xor(sc, 32);
+        const bool other_wins = od < bd || (od == bd && oc < bc);
+        const int loser = other_wins ? bd : od;
         if (other_wins) {
-            bestd = od;
-            bestcol = oc;
+            bd = od;
+            bc = oc;
         }
-        second = min(min(second, os), loser);
-    }
-    if (half == 0) {
-        const int grow = qtile * 32 + lane5;
-        const int na = pw.nrmA[grow] >> 8;
-        const size_t o = pw.row_off + (size_t)it.chunk * pw.nA_pad + grow;
-        rr_d1[o] = bestd >= kDistPad ? INT32_MAX : bestd + na;
-        rr_j1[o] = bestcol;
-        rr_d2[o] = second >= kDistPad ? INT32_MAX : second + na;
+        sc = min(min(sc, os), loser);
+        if (half == 0) {
+            const int grow = (qtile + rb) * 32 + lane5;
+            const int na = pw.nrmA[grow] >> 8;
+            const size_t o = pw.row_off + (size_t)it.chunk * pw.nA_pad + grow;
+            rr_d1[o] = bd >= kDistPad ? INT32_MAX : bd + na;
+            rr_j1[o] = bc;
+            rr_d2[o] = sc >= kDistPad ? INT32_MAX : sc + na;
+        }
     }
 }
 
@@ -292,7 +317,7 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
     const SiftItem it = vitems[xcd_contiguous_item(blockIdx.x, gridDim.x)];
     const SiftPair pw = pairs[it.pair];
     const int ncand = cand.count[it.pair];
-    const int cbase = it.strip * kStripRows;
+    const int cbase = it.strip * kVerifyBlock;
     if (cbase >= ncand) return;  // uniform for the whole workgroup
 
     const int tid = threadIdx.x;

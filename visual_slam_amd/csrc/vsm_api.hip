@@ -179,10 +179,10 @@ int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
         pl.rows += (size_t)sp.nchunks * sp.nA_pad;
         pl.out0 += (size_t)sp.nA;
         pl.out1 += (size_t)sp.nB;
-        for (int s = 0; s < sp.nstrips; ++s) {
+        for (int s = 0; s < sp.nstrips; ++s)
             for (int ch = 0; ch < sp.nchunks; ++ch) pl.items.push_back(SiftItem{p, (int16_t)s, (int16_t)ch});
-            pl.vitems.push_back(SiftItem{p, (int16_t)s, 0});
-        }
+        if (!empty)
+            for (int vb = 0; vb * kVerifyBlock < A->n; ++vb) pl.vitems.push_back(SiftItem{p, (int16_t)vb, 0});
     }
     if ((pl.rows + pl.out0) * kScratchPerRow > kScratchBudget)
         return fail(c, VSM_EINVAL, "submission needs about %zu bytes of scratch (limit %zu); submit fewer pairs per call",

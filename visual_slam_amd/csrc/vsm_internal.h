@@ -20,9 +20,10 @@ namespace vsm {
 // Squared L2 of two u8 descriptors = nrm(a) + nrm(b) - 2*dot(int8 a, int8 b), exact in
 // int32 (< 2^23).
 constexpr int kDescDim = 128;
-constexpr int kRowPad = 256;
+constexpr int kRowPad = 512;
 constexpr int kTileBytes = 4096;      // 32 rows * 128 bytes
-constexpr int kStripRows = 256;       // persistent rows per workgroup (8 waves * 32)
+constexpr int kStripRows = 512;       // query rows per workgroup of the query pass (8 waves * 64)
+constexpr int kVerifyBlock = 256;     // candidates per workgroup of the verify pass (8 waves * 32)
 constexpr int kStepRows = 256;        // streamed rows per main-loop step
 constexpr int kChunkCols = 8192;      // streamed rows per work item of the query-side pass
 constexpr int32_t kNormPad = 0x7FFFFF00;
@@ -43,7 +44,7 @@ struct SiftPair {
 
 struct SiftItem {
     int32_t pair;
-    int16_t strip;   // query pass: 256-row strip of image 0; verify pass: block of 256 candidates
+    int16_t strip;   // query pass: kStripRows-row strip of image 0; verify pass: block of kVerifyBlock candidates
     int16_t chunk;   // query pass: 8192-row chunk of image 1
 };
 
