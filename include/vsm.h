@@ -153,6 +153,13 @@ int vsm_matchtxt_append_dense(const char* path, const char* name0, const char* n
  * trailing-space quirk of main.py:124-129). */
 int vsm_matchtxt_append(const char* path, const char* name0, const char* name1,
                         const int32_t* idx0, const int32_t* idx1, int nm, int n0);
+/* Buffered form of the same writer for long runs (one open file, large writes); the bytes
+ * equal those of repeated vsm_matchtxt_append calls.  truncate != 0 starts a new file. */
+typedef struct vsm_txtwriter vsm_txtwriter;
+vsm_txtwriter* vsm_matchtxt_open(const char* path, int truncate);
+int vsm_matchtxt_write(vsm_txtwriter* w, const char* name0, const char* name1,
+                       const int32_t* idx0, const int32_t* idx1, int nm, int n0);
+int vsm_matchtxt_close(vsm_txtwriter* w);
 /* generate_imagePairs (main.py:157-169).  Returns the pair count. */
 int vsm_image_pairs(int nimages, int consecutive, const int32_t* discrete, int ndiscrete,
                     int32_t* pairs, int cap);

@@ -1,0 +1,57 @@
+"""End to end on the GPU: .sift files in -> vsm_match_pairs (C++ driver over the C ABI) ->
+matching.txt / .mat out, compared with what the CPU oracle produces for the same files."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+import visual_slam_amd as vsm
+from visual_slam_amd import host, synth
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(os.path.dirname(vsm.lib_path()), "vsm_match_pairs")
+
+
+def _make_images(tmp_path, sizes, seed):
+    rng = np.random.default_rng(seed)
+    pool = synth.sift_like(600, rng)
+    imgs = []
+    for i, n in enumerate(sizes):
+        des = synth.sift_like(n, rng)
+        k = min(n, 600) // 2
+        if k:
+            pick = rng.choice(600, k, replace=False)
+            des[rng.choice(n, k, replace=False)] = np.clip(
+                pool[pick].astype(np.int32) + rng.integers(-5, 6, (k, 128)), 0, 255).astype(np.uint8)
+        loc = rng.random((max(n, 1), 5)).astype(np.float32)[:n]
+        if n:
+            host.write_sift(str(tmp_path / ("%d.sift" % i)), loc, des)
+        imgs.append(des)
+    return imgs
+
+
+@pytest.mark.parametrize("mode", ["exhaustive", "window"])
+def test_cli_matches_oracle(tmp_path, mode):
+    sizes = [700, 513, 0, 900, 64, 1100] if mode == "exhaustive" else [300] * 18
+    imgs = _make_images(tmp_path, sizes, seed=21)
+    out = str(tmp_path / "matching.txt")
+    cmd = [CLI, "--sift-dir", str(tmp_path), "--num", str(len(sizes)), "--out", out, "--pairs", mode,
+           "--batch", "7", "--mat"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    if mode == "exhaustive":
+        pairs = [(i, j) for i in range(len(sizes)) for j in range(i + 1, len(sizes))]
+    else:
+        pairs = [tuple(p) for p in orc.image_pairs(len(sizes), 3, [7, 15])]
+    expect = []
+    for a, b in pairs:
+        m0, _ = orc.match_dense_u8(imgs[a], imgs[b], orc.params((4, 5), True))
+        expect.append(orc.matchtxt_record("%d.jpg" % a, "%d.jpg" % b, m0))
+        i0 = np.nonzero(m0 >= 0)[0]
+        ga, gb = host.get_pmatch(str(tmp_path / str(a)), str(tmp_path / str(b)), len(imgs[b]))
+        np.testing.assert_array_equal(ga, i0)
+        np.testing.assert_array_equal(gb, m0[i0])
+    assert open(out).read() == "".join(expect)
+    assert sum(len(e.splitlines()[1].split()) for e in expect) > 100

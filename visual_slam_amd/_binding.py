@@ -74,6 +74,9 @@ SIGNATURES = {
     "vsm_feature_txt_read": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int]),
     "vsm_matchtxt_append_dense": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int]),
     "vsm_matchtxt_append": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "vsm_matchtxt_open": (C.c_void_p, [C.c_char_p, C.c_int]),
+    "vsm_matchtxt_write": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "vsm_matchtxt_close": (C.c_int, [C.c_void_p]),
     "vsm_image_pairs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "vsm_image_pairs_exhaustive": (C.c_longlong, [C.c_int, C.c_void_p, C.c_longlong]),
     "vsm_mat_write_pmatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),

@@ -207,11 +207,9 @@ extern "C" int vsm_feature_txt_read(const char* path, float* xy, int cap)
 // =====================================================================================
 // match txt
 // =====================================================================================
-static int matchtxt_emit(const char* path, const char* name0, const char* name1,
-                         const int32_t* idx0, const int32_t* idx1, int nm, int n0)
+static void matchtxt_format(std::string& rec, const char* name0, const char* name1,
+                            const int32_t* idx0, const int32_t* idx1, int nm, int n0)
 {
-    std::string rec;
-    rec.reserve(64 + (size_t)nm * 14);
     rec.append(name0).append(" ").append(name1).append(" ");
     char num[16];
     rec.append(num, put_int(num, nm) - num);
@@ -225,6 +223,64 @@ static int matchtxt_emit(const char* path, const char* name0, const char* name1,
         }
         rec.push_back('\n');
     }
+}
+
+// Buffered writer for long runs: one open file, records appended in call order, flushed in
+// large writes.  Same bytes as repeated vsm_matchtxt_append calls.
+struct vsm_txtwriter {
+    int fd = -1;
+    std::string buf;
+    bool failed = false;
+    bool flush()
+    {
+        size_t off = 0;
+        while (off < buf.size()) {
+            ssize_t w = ::write(fd, buf.data() + off, buf.size() - off);
+            if (w < 0 && errno == EINTR) continue;
+            if (w <= 0) { failed = true; return false; }
+            off += (size_t)w;
+        }
+        buf.clear();
+        return true;
+    }
+};
+
+extern "C" vsm_txtwriter* vsm_matchtxt_open(const char* path, int truncate)
+{
+    if (!path) return nullptr;
+    const int fd = ::open(path, O_CREAT | O_WRONLY | (truncate ? O_TRUNC : O_APPEND), 0644);
+    if (fd < 0) return nullptr;
+    vsm_txtwriter* w = new vsm_txtwriter();
+    w->fd = fd;
+    w->buf.reserve(8u << 20);
+    return w;
+}
+
+extern "C" int vsm_matchtxt_write(vsm_txtwriter* w, const char* name0, const char* name1,
+                                  const int32_t* idx0, const int32_t* idx1, int nm, int n0)
+{
+    if (!w || !name0 || !name1 || nm < 0 || (nm > 0 && (!idx0 || !idx1))) return VSM_EINVAL;
+    if (w->failed) return VSM_EIO;
+    matchtxt_format(w->buf, name0, name1, idx0, idx1, nm, n0);
+    if (w->buf.size() >= (6u << 20) && !w->flush()) return VSM_EIO;
+    return nm;
+}
+
+extern "C" int vsm_matchtxt_close(vsm_txtwriter* w)
+{
+    if (!w) return VSM_EINVAL;
+    const bool ok = !w->failed && w->flush();
+    ::close(w->fd);
+    delete w;
+    return ok ? VSM_OK : VSM_EIO;
+}
+
+static int matchtxt_emit(const char* path, const char* name0, const char* name1,
+                         const int32_t* idx0, const int32_t* idx1, int nm, int n0)
+{
+    std::string rec;
+    rec.reserve(64 + (size_t)nm * 14);
+    matchtxt_format(rec, name0, name1, idx0, idx1, nm, n0);
     return append_file(path, rec) ? nm : VSM_EIO;
 }
 

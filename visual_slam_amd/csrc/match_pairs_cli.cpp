@@ -1,0 +1,201 @@
+// vsm_match_pairs — command-line driver: a folder of VisualSfM .sift files in, matching.txt
+// (and optionally .mat putative-match records) out.
+//
+// It is the counterpart of the reference's two drivers around the matcher: the batch loop of
+// Others/visualSfM_Sift_file/Match_modified/test_main.cpp:46-60 (files named <i>.sift, i = 0..N-1)
+// and the per-pair loop of Others/SuperPoint_data/main.py:208-280 (pair list, one three-line record
+// per pair appended to matching.txt, image names "<i>.jpg" as main.py:64 assigns them).
+#include "../../include/vsm.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Options {
+    std::string sift_dir, out = "matching.txt", name_ext = ".jpg", sift_ext = ".sift";
+    int num = 0, device = 0, batch = 2048;
+    bool exhaustive = true, mutual = true, write_mat = false, append = false;
+    int consecutive = 3;
+    std::vector<int32_t> discrete{7, 15};
+    int ratio_num = 4, ratio_den = 5;
+    long long max_dist = -1;
+};
+
+void usage()
+{
+    fprintf(stderr,
+            "usage: vsm_match_pairs --sift-dir DIR --num N [options]\n"
+            "  --out FILE            match txt to write (default matching.txt)\n"
+            "  --append              append to FILE instead of starting it\n"
+            "  --pairs exhaustive|window   all i<j pairs (default) or the reference's window list\n"
+            "  --consecutive K       window list: pairs (i, i+1..i+K)          (default 3)\n"
+            "  --discrete A,B,...    window list: pairs (i, i+A), (i, i+B) ... (default 7,15)\n"
+            "  --ratio NUM/DEN       Lowe ratio, exact rational (default 4/5; 0/1 disables)\n"
+            "  --max-dist D          keep matches with squared distance <= D\n"
+            "  --no-mutual           skip the mutual-nearest-neighbour check\n"
+            "  --mat                 also write <DIR>/<i>.mat putative-match records\n"
+            "  --name-ext EXT        image-name suffix in the match txt (default .jpg)\n"
+            "  --device N, --batch P (pairs per GPU submission, default 2048)\n");
+}
+
+bool parse(int argc, char** argv, Options& o)
+{
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&](const char* what) -> const char* {
+            if (i + 1 >= argc) {
+                fprintf(stderr, "missing value for %s\n", what);
+                return nullptr;
+            }
+            return argv[++i];
+        };
+        const char* v = nullptr;
+        if (a == "--sift-dir") { if (!(v = next("--sift-dir"))) return false; o.sift_dir = v; }
+        else if (a == "--num") { if (!(v = next("--num"))) return false; o.num = atoi(v); }
+        else if (a == "--out") { if (!(v = next("--out"))) return false; o.out = v; }
+        else if (a == "--append") o.append = true;
+        else if (a == "--pairs") { if (!(v = next("--pairs"))) return false; o.exhaustive = strcmp(v, "window") != 0; }
+        else if (a == "--consecutive") { if (!(v = next("--consecutive"))) return false; o.consecutive = atoi(v); }
+        else if (a == "--discrete") {
+            if (!(v = next("--discrete"))) return false;
+            o.discrete.clear();
+            for (const char* p = v; *p;) {
+                o.discrete.push_back((int32_t)strtol(p, const_cast<char**>(&p), 10));
+                if (*p == ',') ++p;
+            }
+        }
+        else if (a == "--ratio") {
+            if (!(v = next("--ratio"))) return false;
+            if (sscanf(v, "%d/%d", &o.ratio_num, &o.ratio_den) != 2) { fprintf(stderr, "--ratio wants NUM/DEN\n"); return false; }
+        }
+        else if (a == "--max-dist") { if (!(v = next("--max-dist"))) return false; o.max_dist = atoll(v); }
+        else if (a == "--no-mutual") o.mutual = false;
+        else if (a == "--mat") o.write_mat = true;
+        else if (a == "--name-ext") { if (!(v = next("--name-ext"))) return false; o.name_ext = v; }
+        else if (a == "--device") { if (!(v = next("--device"))) return false; o.device = atoi(v); }
+        else if (a == "--batch") { if (!(v = next("--batch"))) return false; o.batch = atoi(v); }
+        else { fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
+    }
+    return !o.sift_dir.empty() && o.num > 0 && o.batch > 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    Options o;
+    if (!parse(argc, argv, o)) {
+        usage();
+        return 2;
+    }
+    vsm_ctx* ctx = vsm_create(o.device);
+    if (!ctx) {
+        fprintf(stderr, "vsm_create: %s\n", vsm_last_error(nullptr));
+        return 1;
+    }
+    const auto t_start = std::chrono::steady_clock::now();
+
+    // ---- load and upload every image's descriptors once
+    std::vector<int> set_id(o.num, -1), count(o.num, 0);
+    std::vector<uint8_t> des;
+    for (int i = 0; i < o.num; ++i) {
+        const std::string path = o.sift_dir + "/" + std::to_string(i) + o.sift_ext;
+        int np = 0, nloc = 0;
+        if (!vsm_sift_read(path.c_str(), nullptr, nullptr, 0, &np, &nloc)) np = 0;  // unreadable or empty
+        des.resize((size_t)np * VSM_DESC_DIM_U8 + 1);
+        if (np > 0 && !vsm_sift_read(path.c_str(), nullptr, des.data(), np, nullptr, nullptr)) {
+            fprintf(stderr, "short read: %s\n", path.c_str());
+            return 1;
+        }
+        count[i] = np;
+        set_id[i] = vsm_upload_u8(ctx, des.data(), np);
+        if (set_id[i] < 0) {
+            fprintf(stderr, "upload %s: %s\n", path.c_str(), vsm_last_error(ctx));
+            return 1;
+        }
+    }
+
+    // ---- pair list
+    std::vector<int32_t> pairs;
+    long long npairs;
+    if (o.exhaustive) {
+        npairs = vsm_image_pairs_exhaustive(o.num, nullptr, 0);
+        pairs.resize((size_t)npairs * 2 + 2);
+        vsm_image_pairs_exhaustive(o.num, pairs.data(), npairs);
+    } else {
+        npairs = vsm_image_pairs(o.num, o.consecutive, o.discrete.data(), (int)o.discrete.size(), nullptr, 0);
+        pairs.resize((size_t)npairs * 2 + 2);
+        vsm_image_pairs(o.num, o.consecutive, o.discrete.data(), (int)o.discrete.size(), pairs.data(), (int)npairs);
+    }
+
+    vsm_txtwriter* tw = vsm_matchtxt_open(o.out.c_str(), o.append ? 0 : 1);
+    if (!tw) {
+        fprintf(stderr, "cannot open %s\n", o.out.c_str());
+        return 1;
+    }
+    vsm_params prm{};
+    prm.ratio_num = o.ratio_num;
+    prm.ratio_den = o.ratio_den;
+    prm.mutual = o.mutual ? 1 : 0;
+    prm.max_dist_sq = o.max_dist;
+    prm.min_score = -1e30f;
+    prm.max_dist_sq_f = -1.0f;
+
+    std::vector<int32_t> ids, idx0, idx1;
+    std::vector<int64_t> off;
+    long long total = 0;
+    for (long long lo = 0; lo < npairs; lo += o.batch) {
+        const int take = (int)std::min<long long>(o.batch, npairs - lo);
+        ids.resize((size_t)take * 2);
+        size_t cap = 1;
+        for (int k = 0; k < take; ++k) {
+            const int a = pairs[2 * (lo + k)], b = pairs[2 * (lo + k) + 1];
+            ids[2 * k] = set_id[a];
+            ids[2 * k + 1] = set_id[b];
+            cap += (size_t)count[a];
+        }
+        idx0.resize(cap);
+        idx1.resize(cap);
+        off.resize((size_t)take + 1);
+        const long long got = vsm_match_pairs(ctx, ids.data(), take, &prm, VSM_METRIC_L2, off.data(),
+                                              idx0.data(), idx1.data(), (long long)cap);
+        if (got < 0) {
+            fprintf(stderr, "vsm_match_pairs: %s\n", vsm_last_error(ctx));
+            return 1;
+        }
+        total += got;
+        for (int k = 0; k < take; ++k) {
+            const int a = pairs[2 * (lo + k)], b = pairs[2 * (lo + k) + 1];
+            const int nm = (int)(off[k + 1] - off[k]);
+            const std::string n0 = std::to_string(a) + o.name_ext, n1 = std::to_string(b) + o.name_ext;
+            if (vsm_matchtxt_write(tw, n0.c_str(), n1.c_str(), idx0.data() + off[k], idx1.data() + off[k], nm, count[a]) < 0) {
+                fprintf(stderr, "write error on %s\n", o.out.c_str());
+                return 1;
+            }
+            if (o.write_mat) {
+                const std::string p0 = o.sift_dir + "/" + std::to_string(a), p1 = o.sift_dir + "/" + std::to_string(b);
+                const int rc = vsm_mat_write_pmatch(p0.c_str(), p1.c_str(), count[a], count[b], nm,
+                                                    idx0.data() + off[k], idx1.data() + off[k], o.num);
+                if (rc < 0) {
+                    fprintf(stderr, "cannot write .mat for pair %d %d (%d)\n", a, b, rc);
+                    return 1;
+                }
+            }
+        }
+    }
+    if (vsm_matchtxt_close(tw) != VSM_OK) {
+        fprintf(stderr, "write error on %s\n", o.out.c_str());
+        return 1;
+    }
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    fprintf(stderr, "%d images, %lld pairs, %lld matches, %.3f s (%.0f pairs/s)\n", o.num, npairs, total, secs,
+            npairs / secs);
+    vsm_destroy(ctx);
+    return 0;
+}
