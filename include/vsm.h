@@ -79,6 +79,17 @@ int vsm_upload_u8_device(vsm_ctx* ctx, const void* des_dev, int n);
  * form main.py:255 makes.  1 <= dim <= 256. */
 int vsm_upload_f32(vsm_ctx* ctx, const float* des, int n, int dim, int layout);
 int vsm_upload_f32_device(vsm_ctx* ctx, const void* des_dev, int n, int dim, int layout);
+/* How float sets are searched.  Both modes return the same bits: scores are the
+ * k-ascending single-precision fma chain, ties go to the lowest index (the torch
+ * max/argmin convention of superglue.py:276-279 and model_2_0.py:64).
+ *   VSM_F32_FAST_EXACT (default): bf16 matrix-core pass that keeps a proven superset of
+ *     each query's two best rows, then an exact re-rank of the survivors; falls back to
+ *     the f32 kernel by itself when a survivor list overflows (massively tied scores).
+ *   VSM_F32_MFMA_F32: every score on the f32-input matrix cores. */
+enum { VSM_F32_FAST_EXACT = 0, VSM_F32_MFMA_F32 = 1 };
+int vsm_set_f32_mode(vsm_ctx* ctx, int mode);
+/* Which of the two ran in the last float search on this context (-1: none yet). */
+int vsm_last_f32_path(const vsm_ctx* ctx);
 int vsm_release_set(vsm_ctx* ctx, int set);
 int vsm_set_count(const vsm_ctx* ctx, int set);
 

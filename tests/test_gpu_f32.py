@@ -19,6 +19,14 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+@pytest.fixture(autouse=True, params=[vsm.F32_FAST_EXACT, vsm.F32_MFMA_F32], ids=["bf16+rerank", "f32mfma"])
+def f32_mode(matcher, request):
+    """Every test runs twice: bf16 coarse pass + exact re-rank, and the f32 matrix-core kernel alone."""
+    matcher.set_f32_mode(request.param)
+    yield request.param
+    matcher.set_f32_mode(vsm.F32_FAST_EXACT)
+
+
 def _knn_check(matcher, a, b, metric):
     s0, s1 = matcher.upload_f32(a), matcher.upload_f32(b)
     try:
@@ -157,3 +165,39 @@ def test_database_slices_merge(matcher):
         np.testing.assert_array_equal(ok1, o1)
         np.testing.assert_array_equal(ok2, o2)
     matcher.release(sq)
+
+
+def test_fast_path_is_the_one_that_runs(matcher, f32_mode):
+    a, b = synth.superpoint_pair(3000, 20000, 256, seed=31)
+    for metric in (vsm.METRIC_DOT, vsm.METRIC_L2):
+        _knn_check(matcher, a, b, metric)
+        assert matcher.last_f32_path() == f32_mode
+
+
+def test_scaled_and_clustered_vectors(matcher):
+    """Norms far from 1 and tight clusters: the coarse margin scales with |a| max|b|."""
+    rng = np.random.default_rng(32)
+    centers = synth.unit_f32(40, 256, rng)
+    b = (centers[rng.integers(0, 40, 6000)] + 0.02 * rng.standard_normal((6000, 256))).astype(np.float32)
+    a = (centers[rng.integers(0, 40, 900)] + 0.02 * rng.standard_normal((900, 256))).astype(np.float32)
+    b *= rng.uniform(0.01, 30.0, (6000, 1)).astype(np.float32)
+    a *= rng.uniform(0.5, 900.0, (900, 1)).astype(np.float32)
+    a[17] = 0.0
+    for metric in (vsm.METRIC_DOT, vsm.METRIC_L2):
+        _knn_check(matcher, a, b, metric)
+
+
+def test_survivor_overflow_falls_back(matcher, f32_mode):
+    """40000 copies of one row tie on every query: the survivor lists overflow and the exact kernel takes over."""
+    rng = np.random.default_rng(33)
+    a = synth.unit_f32(2000, 256, rng)
+    b = np.repeat(synth.unit_f32(1, 256, rng), 40000, axis=0)
+    b[4000] = a[3]
+    for metric in (vsm.METRIC_DOT, vsm.METRIC_L2):
+        _knn_check(matcher, a, b, metric)
+        assert matcher.last_f32_path() == vsm.F32_MFMA_F32
+    # rows sorted so that every next one scores higher for query 0: each one is appended
+    t = np.linspace(0.0, 1.0, 40000, dtype=np.float32)[:, None]
+    b2 = (t * a[0] + (1 - t) * a[1]).astype(np.float32)
+    _knn_check(matcher, a, b2, vsm.METRIC_DOT)
+    assert matcher.last_f32_path() == vsm.F32_MFMA_F32

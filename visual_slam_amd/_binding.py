@@ -8,6 +8,8 @@ import numpy as np
 METRIC_DOT, METRIC_L2 = 0, 1
 LAYOUT_ROWS, LAYOUT_DIM_MAJOR = 0, 1
 NO_SECOND = 2**31 - 1
+F32_FAST_EXACT = 0
+F32_MFMA_F32 = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -50,6 +52,8 @@ SIGNATURES = {
     "vsm_upload_u8_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "vsm_upload_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vsm_upload_f32_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "vsm_set_f32_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "vsm_last_f32_path": (C.c_int, [C.c_void_p]),
     "vsm_release_set": (C.c_int, [C.c_void_p, C.c_int]),
     "vsm_set_count": (C.c_int, [C.c_void_p, C.c_int]),
     "vsm_match_pair": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_int,
@@ -259,6 +263,13 @@ class Matcher:
         return (res.reshape(x.shape) if want_result else None), argmin.reshape((b,) + tuple(x.shape[2:]))
 
     # ---- measurement --------------------------------------------------------------------
+    def set_f32_mode(self, mode):
+        """0 = bf16 coarse pass + exact re-rank (default), 1 = f32 matrix cores only; same results."""
+        self._check(self._l.vsm_set_f32_mode(self._h, int(mode)))
+
+    def last_f32_path(self):
+        return int(self._l.vsm_last_f32_path(self._h))
+
     def set_timing(self, on=True):
         self._check(self._l.vsm_set_timing(self._h, 1 if on else 0))
 

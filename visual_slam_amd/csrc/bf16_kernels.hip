@@ -1,0 +1,487 @@
+// Fast path for float descriptors: a bf16-MFMA coarse pass that keeps a PROVABLE superset of the
+// two best rows of every query, followed by an exact single-precision re-rank of the few survivors.
+// The result equals the exact-f32 path bit for bit (the re-rank evaluates the same k-ascending fmaf
+// chain, and both of the true best rows are guaranteed to be among the survivors).
+//
+// Error bound.  With a^ = bf16(a), b^ = bf16(b) (round to nearest: |x^ - x| <= 2^-9 |x|) the coarse
+// dot product differs from the real one by at most (2^-8 + 2^-18) sum|a_k b_k| <= 2^-8 (1 + 2^-10)
+// |a||b|; f32 accumulation of 256 bf16 products and the f32 rounding of the exact chain add at most
+// 3 * 256 * 2^-24 |a||b|.  eps(i) = kCoarseEps * |a_i| * max_j |b_j| covers both with room to spare.
+// Let T2 be the second largest coarse score of query i.  Every row whose exact score is at least the
+// exact runner-up has coarse score >= T2 - 2 eps.  The coarse pass appends every row that beats the
+// RUNNING T2 (of the rows one lane has seen) minus that margin, which only grows, so the lists hold
+// a superset; the re-rank filters with the final T2.  For the L2 ranking the coarse keys are
+// dot - |b|^2 / 2 (half the exact key; the accumulators start from -|b|^2 / 2), which adds the f32
+// rounding of partial sums of that size: 2 * 256 * 2^-24 * max|b|^2 / 2 on top of 2 eps.
+// Inputs are assumed finite and far from the ends of the f32 exponent range.
+#include "f32_kernels.h"
+
+#include <math.h>
+
+#include <algorithm>
+#include <type_traits>
+
+namespace vsm {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+#define VSM_LDS __attribute__((address_space(3)))
+#define VSM_GLB __attribute__((address_space(1)))
+
+constexpr float kCoarseEps = 0.0041f;
+
+__device__ __forceinline__ float coarse_margin(bool l2, float na_sq, float maxnb_sq)
+{
+    const float eps = kCoarseEps * sqrtf(na_sq) * sqrtf(maxnb_sq);
+    return l2 ? 2.0f * eps + 3.1e-5f * maxnb_sq : 2.0f * eps;
+}
+
+// ---------------------------------------------------------------------------------
+// f32 rows -> bf16 operand-order shadow (+ largest row norm of the set)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f32_to_bf16_rne(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+__global__ void bf16_transform_kernel(const float* __restrict__ src, int n, int n_pad, int dim, int dimp,
+                                      int dim_major, unsigned short* __restrict__ shadow)
+{
+    // one thread per (row, k-step, half): 8 consecutive k
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int steps = dimp / 16;
+    const long long total = (long long)n_pad * steps * 2;
+    if (gid >= total) return;
+    const int h = (int)(gid & 1);
+    const int s = (int)((gid >> 1) % steps);
+    const int row = (int)((gid >> 1) / steps);
+    unsigned v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * s + 8 * h + j;
+        float x = 0.0f;
+        if (row < n && k < dim) x = dim_major ? src[(size_t)k * n + row] : src[(size_t)row * dim + k];
+        v[j] = f32_to_bf16_rne(x);
+    }
+    const int tile = row >> 5, r = row & 31;
+    uint4 out;
+    out.x = v[0] | (v[1] << 16);
+    out.y = v[2] | (v[3] << 16);
+    out.z = v[4] | (v[5] << 16);
+    out.w = v[6] | (v[7] << 16);
+    *reinterpret_cast<uint4*>(shadow + ((size_t)tile * steps + s) * 512 + (h * 32 + r) * 8) = out;
+}
+
+__global__ void max_norm_kernel(const float* __restrict__ nrm, int n, int n_slots, float* __restrict__ out_maxnorm,
+                                float* __restrict__ init_l2, float* __restrict__ init_dot)
+{
+    float m = 0.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += gridDim.x * blockDim.x) {
+        const bool real = i < n;
+        const float v = real ? nrm[i] : 0.0f;
+        m = fmaxf(m, v);
+        init_l2[i] = real ? -0.5f * v : -INFINITY;
+        init_dot[i] = real ? 0.0f : -INFINITY;
+    }
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    // squared norms are >= 0, so their bit patterns order like unsigned integers
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out_maxnorm), __float_as_uint(m));
+}
+
+void launch_bf16_transform(const float* src, int n, int n_pad, int dim, bool dim_major, void* shadow_base,
+                           const float* nrm, hipStream_t s)
+{
+    const Bf16Shadow v = bf16_shadow_view(shadow_base, n_pad, dim);
+    unsigned short* shadow = const_cast<unsigned short*>(v.rows);
+    float* maxnorm_sq = const_cast<float*>(v.maxnorm_sq);
+    const int dimp = f32_dimp(dim);
+    const long long total = (long long)n_pad * (dimp / 16) * 2;
+    hipLaunchKernelGGL(bf16_transform_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       src, n, n_pad, dim, dimp, dim_major ? 1 : 0, shadow);
+    (void)hipMemsetAsync(maxnorm_sq, 0, sizeof(float), s);
+    const int slots = n_pad + 64;
+    hipLaunchKernelGGL(max_norm_kernel, dim3(std::min(64, (slots + 255) / 256)), dim3(256), 0, s, nrm, n, slots,
+                       maxnorm_sq, const_cast<float*>(v.init_l2), const_cast<float*>(v.init_dot));
+}
+
+// ---------------------------------------------------------------------------------
+// coarse pass
+// ---------------------------------------------------------------------------------
+struct CoarsePart {   // per (split, query, lane half): coarse top-2 values and list length
+    float t1, t2;
+    int count;
+    int pad;
+};
+
+// Workgroup = 4 waves; wave w keeps the bf16 operands of kCoarseRB x 32 queries in registers (the
+// accumulator's lane axis), the database streams through LDS in 32 KiB steps (LDS-DMA, double
+// buffered) and every tile read from LDS feeds kCoarseRB MFMA chains.
+constexpr int kCoarseRB = 2;
+constexpr int kCoarseWaves = 4;
+constexpr int kCoarseStripRows = kCoarseWaves * kCoarseRB * 32;  // queries per workgroup
+constexpr int kCoarseStepBytes = 32768;
+static_assert(kF32RowPad % kCoarseStripRows == 0, "query strips must tile the padded row count");
+
+// The accumulators start from a per-row constant instead of zero: -|b|^2 / 2 for the L2 ranking (the
+// coarse key is then dot - |b|^2 / 2, half the exact key), 0 for the dot ranking, and -inf for the
+// padding rows past the end of the set, which therefore never rank.  The kernel itself is the same
+// for both rankings.
+template <int DIMP>
+__global__ __launch_bounds__(kCoarseWaves * 64, 2)
+void bf16_coarse_kernel(F32Problem pr, const unsigned short* __restrict__ bfA, const unsigned short* __restrict__ bfB,
+                        const float* __restrict__ initB, const float* __restrict__ maxnormB_sq, int nstrips,
+                        int tiles_per_split, CoarsePart* __restrict__ part, uint2* __restrict__ lists,
+                        int* __restrict__ overflow)
+{
+    constexpr int S = DIMP / 16;             // k-steps (MFMAs) per tile
+    constexpr int RB = kCoarseRB;
+    constexpr int TILE_BYTES = 32 * DIMP * 2;
+    constexpr int STEP_TILES = kCoarseStepBytes / TILE_BYTES;   // 2, 4 or 8
+    constexpr int STEP_ROWS = STEP_TILES * 32;
+    // database steps, double buffered; the two buffers and the two constant arrays are addressed with
+    // compile-time indices so that reads of one are known not to touch the DMA target of the other
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) float s_init0[256];
+    __shared__ __attribute__((aligned(16))) float s_init1[256];
+
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int split = L / nstrips, strip = L % nstrips;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane5 = lane & 31, half = lane >> 5;
+    const bool l2 = pr.metric == 1;
+    const float maxnb = *maxnormB_sq;
+
+    // persistent operands: this wave's RB x 32 queries
+    v8bf qf[RB][S];
+    float margin[RB], thr[RB], b1[RB], b2[RB];
+    int cnt[RB];
+    const int qidx0 = ((strip * kCoarseWaves + wave) * RB) * 32 + lane5;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int qtile = (strip * kCoarseWaves + wave) * RB + rb;
+        const v8bf* src = reinterpret_cast<const v8bf*>(bfA + (size_t)qtile * S * 512) + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) qf[rb][s] = src[s * 64];
+        const int qi = qidx0 + rb * 32;
+        margin[rb] = coarse_margin(l2, pr.nrmA[qi], maxnb);
+        // padded queries never append
+        thr[rb] = qi < pr.nA ? -INFINITY : INFINITY;
+        if (qi >= pr.nA) margin[rb] = -INFINITY;
+        b1[rb] = -INFINITY;
+        b2[rb] = -INFINITY;
+        cnt[rb] = 0;
+    }
+
+    const int ntiles = pr.nB_pad >> 5;
+    const int t0 = split * tiles_per_split;                       // multiples of 8 tiles, as is ntiles
+    const int t1e = min(t0 + tiles_per_split, ntiles);
+    const int nsteps = (t1e - t0) / STEP_TILES;
+
+    auto stage = [&](auto BUF, int st) {
+        constexpr int buf = decltype(BUF)::value;
+        const int tile = t0 + st * STEP_TILES;
+        const char* src = reinterpret_cast<const char*>(bfB) + (size_t)tile * TILE_BYTES + lane * 16;
+        char* dst = smem + buf * kCoarseStepBytes;
+#pragma unroll
+        for (int p = 0; p < kCoarseStepBytes / 1024 / kCoarseWaves; ++p) {
+            const int piece = wave + p * kCoarseWaves;
+            __builtin_amdgcn_global_load_lds((const VSM_GLB void*)(src + piece * 1024),
+                                             (VSM_LDS void*)(dst + piece * 1024), 16, 0, 0);
+        }
+        if (wave * 64 < STEP_ROWS)
+            __builtin_amdgcn_global_load_lds((const VSM_GLB void*)(initB + tile * 32 + wave * 64 + lane),
+                                             (VSM_LDS void*)((buf ? s_init1 : s_init0) + wave * 64), 4, 0, 0);
+    };
+
+    auto compute = [&](auto BUF, int st) {
+        constexpr int buf = decltype(BUF)::value;
+        const float* s_init = buf ? s_init1 : s_init0;
+#pragma unroll 2
+        for (int tt = 0; tt < STEP_TILES; ++tt) {
+            const int tile = t0 + st * STEP_TILES + tt;
+            const v8bf* At = reinterpret_cast<const v8bf*>(smem + buf * kCoarseStepBytes + tt * TILE_BYTES) + lane;
+            v16f acc[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = *reinterpret_cast<const float4*>(s_init + tt * 32 + 8 * g + 4 * half);
+                    acc[rb][4 * g] = v.x; acc[rb][4 * g + 1] = v.y; acc[rb][4 * g + 2] = v.z; acc[rb][4 * g + 3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const v8bf a = At[s * 64];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[rb][s], acc[rb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x0 = acc[rb][2 * e], x1 = acc[rb][2 * e + 1];
+                    const float u = __builtin_amdgcn_fmed3f(b1[rb], x0, x1);
+                    b1[rb] = fmaxf(fmaxf(b1[rb], x0), x1);
+                    tmax = fmaxf(fmaxf(tmax, x0), x1);
+                    b2[rb] = fmaxf(b2[rb], u);
+                }
+                if (__ballot(tmax >= thr[rb])) {
+                    // rare: append every row that reaches the threshold as it stood BEFORE this tile
+                    uint2* mylist = lists + (((size_t)split * pr.nA_pad + qidx0 + rb * 32) * 2 + half) * kCoarseCap;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float x = acc[rb][reg];
+                        if (x >= thr[rb] && x > -INFINITY) {
+                            const int rin = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                            if (cnt[rb] < kCoarseCap)
+                                mylist[cnt[rb]] = make_uint2((unsigned)(tile * 32 + rin), __float_as_uint(x));
+                            ++cnt[rb];
+                        }
+                    }
+                }
+                thr[rb] = b2[rb] - margin[rb];   // +inf for padded queries
+            }
+        }
+    };
+
+    using Buf0 = std::integral_constant<int, 0>;
+    using Buf1 = std::integral_constant<int, 1>;
+    if (nsteps > 0) stage(Buf0{}, 0);
+    __syncthreads();
+    for (int st = 0; st < nsteps; st += 2) {
+        if (st + 1 < nsteps) stage(Buf1{}, st + 1);
+        compute(Buf0{}, st);
+        __syncthreads();
+        if (st + 1 < nsteps) {
+            if (st + 2 < nsteps) stage(Buf0{}, st + 2);
+            compute(Buf1{}, st + 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        if (cnt[rb] > kCoarseCap) atomicOr(overflow, 1);
+        CoarsePart cp;
+        cp.t1 = b1[rb]; cp.t2 = b2[rb]; cp.count = min(cnt[rb], kCoarseCap); cp.pad = 0;
+        part[((size_t)split * pr.nA_pad + qidx0 + rb * 32) * 2 + half] = cp;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// exact re-rank of the survivors
+// ---------------------------------------------------------------------------------
+// One wave per query.  Lane l first folds the coarse top-2 of sublist l into the query's final coarse
+// runner-up T2, then the wave walks the concatenated survivor lists 64 entries at a time, keeps the
+// entries with coarse score >= T2 - margin, and scores those exactly: one lane per surviving row runs
+// the k-ascending fmaf chain on the f32 rows (fragment-major layout: in group g, float4 number
+// g*64 + h*32 + r of a tile holds k = 8g + h, 8g + 2 + h, 8g + 4 + h, 8g + 6 + h of row r).
+constexpr int kRerankWaves = 4;
+
+struct Best2 {
+    float s1, s2;
+    int r1, r2;
+};
+
+__device__ __forceinline__ bool ranks_before(float x, int jx, float y, int jy)
+{
+    return x > y || (x == y && (unsigned)jx < (unsigned)jy);
+}
+
+__device__ __forceinline__ void best2_insert(Best2& b, float sc, int row)
+{
+    if (ranks_before(sc, row, b.s1, b.r1)) {
+        b.s2 = b.s1; b.r2 = b.r1;
+        b.s1 = sc; b.r1 = row;
+    } else if (ranks_before(sc, row, b.s2, b.r2)) {
+        b.s2 = sc; b.r2 = row;
+    }
+}
+
+__device__ __forceinline__ float exact_dot(const float* fragA, const float* fragB, int dimp, int ia, int ib)
+{
+    const float4* pa = reinterpret_cast<const float4*>(fragA + (size_t)(ia >> 5) * 32 * dimp) + (ia & 31);
+    const float4* pb = reinterpret_cast<const float4*>(fragB + (size_t)(ib >> 5) * 32 * dimp) + (ib & 31);
+    float d = 0.0f;
+    for (int g = 0; g < dimp / 8; ++g) {
+        const float4 a0 = pa[g * 64], a1 = pa[g * 64 + 32];
+        const float4 b0 = pb[g * 64], b1 = pb[g * 64 + 32];
+        d = fmaf(b0.x, a0.x, d); d = fmaf(b1.x, a1.x, d);
+        d = fmaf(b0.y, a0.y, d); d = fmaf(b1.y, a1.y, d);
+        d = fmaf(b0.z, a0.z, d); d = fmaf(b1.z, a1.z, d);
+        d = fmaf(b0.w, a0.w, d); d = fmaf(b1.w, a1.w, d);
+    }
+    return d;
+}
+
+__global__ __launch_bounds__(kRerankWaves * 64)
+void bf16_rerank_kernel(F32Problem pr, const float* __restrict__ maxnormB_sq, int nsplits,
+                        const CoarsePart* __restrict__ part, const uint2* __restrict__ lists,
+                        int32_t* __restrict__ j1, int32_t* __restrict__ j2,
+                        float* __restrict__ k1, float* __restrict__ k2)
+{
+    __shared__ int s_rows[kRerankWaves][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * kRerankWaves + wave;
+    if (i >= pr.nA) return;   // the whole wave leaves; no workgroup barrier below
+    volatile int* rows = s_rows[wave];
+    const bool l2 = pr.metric == 1;
+    const int dimp = f32_dimp(pr.dim);
+    const float na = pr.nrmA[i];
+    const float margin = coarse_margin(l2, na, *maxnormB_sq);
+    const int nsub = nsplits * 2;
+    auto sub_index = [&](int sid) { return ((size_t)(sid >> 1) * pr.nA_pad + i) * 2 + (sid & 1); };
+
+    // final coarse runner-up over all splits and both lane halves
+    float T1 = -INFINITY, T2 = -INFINITY;
+    for (int sid = lane; sid < nsub; sid += 64) {
+        const CoarsePart cp = part[sub_index(sid)];
+        T2 = fmaxf(fmaxf(T2, cp.t2), fminf(T1, cp.t1));
+        T1 = fmaxf(T1, cp.t1);
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const float o1 = __shfl_xor(T1, m), o2 = __shfl_xor(T2, m);
+        T2 = fmaxf(fmaxf(T2, o2), fminf(T1, o1));
+        T1 = fmaxf(T1, o1);
+    }
+    const float thr = T2 - margin;
+
+    Best2 best;
+    best.s1 = -INFINITY; best.s2 = -INFINITY; best.r1 = -1; best.r2 = -1;
+    int npending = 0;   // wave-uniform: rows waiting in `rows`
+    auto flush = [&]() {
+        if (lane < npending) {
+            const int row = rows[lane];
+            const float d = exact_dot(pr.fragA, pr.fragB, dimp, i, row);
+            const float sc = l2 ? fmaf(2.0f, d, -pr.nrmB[row]) : d;
+            if (sc > -INFINITY) best2_insert(best, sc, row);
+        }
+        npending = 0;
+    };
+
+    for (int chunk = 0; chunk < nsub; chunk += 64) {
+        const int sid = chunk + lane;
+        const int cnt = sid < nsub ? part[sub_index(sid)].count : 0;
+        int incl = cnt;   // inclusive prefix sum of the chunk's list lengths
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        const int total = __shfl(incl, 63);
+        for (int e0 = 0; e0 < total; e0 += 64) {
+            const int e = e0 + lane;
+            // sublist of flat entry e: the first lane whose inclusive prefix exceeds e
+            int lo = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int probe = __shfl(incl, lo + step - 1);
+                if (probe <= e) lo += step;
+            }
+            lo = min(lo, 63);
+            const int within = e - (__shfl(incl, lo) - __shfl(cnt, lo));
+            bool keep = false;
+            int row = 0;
+            if (e < total) {
+                const uint2 en = lists[sub_index(chunk + lo) * kCoarseCap + within];
+                keep = __uint_as_float(en.y) >= thr;
+                row = (int)en.x;
+            }
+            const unsigned long long mask = __ballot(keep);
+            const int n = __popcll(mask);
+            if (n == 0) continue;
+            if (npending + n > 64) flush();
+            if (keep) rows[npending + __popcll(mask & ((1ull << lane) - 1ull))] = row;
+            npending += n;
+        }
+    }
+    flush();
+
+    // lanes hold disjoint rows: merge by (score descending, row ascending)
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        Best2 o;
+        o.s1 = __shfl_xor(best.s1, m); o.s2 = __shfl_xor(best.s2, m);
+        o.r1 = __shfl_xor(best.r1, m); o.r2 = __shfl_xor(best.r2, m);
+        if (o.r1 >= 0) best2_insert(best, o.s1, o.r1);
+        if (o.r2 >= 0) best2_insert(best, o.s2, o.r2);
+    }
+    if (lane == 0) {
+        j1[i] = best.r1;
+        j2[i] = best.r2;
+        k1[i] = best.r1 < 0 ? (l2 ? INFINITY : -INFINITY) : (l2 ? fmaxf(-best.s1 + na, 0.0f) : best.s1);
+        k2[i] = best.r2 < 0 ? (l2 ? INFINITY : -INFINITY) : (l2 ? fmaxf(-best.s2 + na, 0.0f) : best.s2);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------------
+static void coarse_geometry(const F32Problem& pr, int* nstrips, int* nsplits, int* tiles_per_split)
+{
+    const int ntiles = pr.nB_pad / 32;
+    *nstrips = pr.nA_pad / kCoarseStripRows;
+    int want = (1024 + *nstrips - 1) / *nstrips;   // >= 1024 workgroups of 4 waves when the database allows
+    int tps = (ntiles + want - 1) / want;
+    tps = (tps + 7) & ~7;                          // whole LDS steps at every dimension
+    *tiles_per_split = tps;
+    *nsplits = (ntiles + tps - 1) / tps;
+}
+
+static size_t part_bytes(size_t per) { return (per * sizeof(CoarsePart) + 255) & ~(size_t)255; }
+
+size_t bf16_scratch_bytes(const F32Problem& pr)
+{
+    int nstrips, nsplits, tps;
+    coarse_geometry(pr, &nstrips, &nsplits, &tps);
+    const size_t per = (size_t)nsplits * pr.nA_pad * 2;
+    return part_bytes(per) + per * kCoarseCap * sizeof(uint2);
+}
+
+template <int DIMP>
+static void launch_coarse_t(const F32Problem& pr, const unsigned short* bfA, const unsigned short* bfB,
+                            const float* initB, const float* maxnormB_sq, int nstrips, int nsplits, int tps,
+                            CoarsePart* part, uint2* lists, int* overflow, hipStream_t s)
+{
+    const int lds = 2 * kCoarseStepBytes;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_coarse_kernel<DIMP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(bf16_coarse_kernel<DIMP>, dim3(nstrips * nsplits), dim3(kCoarseWaves * 64), lds, s,
+                       pr, bfA, bfB, initB, maxnormB_sq, nstrips, tps, part, lists, overflow);
+}
+
+void launch_bf16_knn(const F32Problem& pr, const Bf16Shadow& shA, const Bf16Shadow& shB,
+                     int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow, hipStream_t s)
+{
+    const unsigned short* bfA = shA.rows;
+    const unsigned short* bfB = shB.rows;
+    const float* maxnormB_sq = shB.maxnorm_sq;
+    const float* initB = pr.metric == 1 ? shB.init_l2 : shB.init_dot;
+    int nstrips, nsplits, tps;
+    coarse_geometry(pr, &nstrips, &nsplits, &tps);
+    const size_t per = (size_t)nsplits * pr.nA_pad * 2;
+    CoarsePart* part = static_cast<CoarsePart*>(scratch);
+    uint2* lists = reinterpret_cast<uint2*>(static_cast<char*>(scratch) + part_bytes(per));
+    const int dimp = f32_dimp(pr.dim);
+    if (dimp == 64) launch_coarse_t<64>(pr, bfA, bfB, initB, maxnormB_sq, nstrips, nsplits, tps, part, lists, overflow, s);
+    else if (dimp == 128) launch_coarse_t<128>(pr, bfA, bfB, initB, maxnormB_sq, nstrips, nsplits, tps, part, lists, overflow, s);
+    else launch_coarse_t<256>(pr, bfA, bfB, initB, maxnormB_sq, nstrips, nsplits, tps, part, lists, overflow, s);
+    hipLaunchKernelGGL(bf16_rerank_kernel, dim3((pr.nA + kRerankWaves - 1) / kRerankWaves), dim3(kRerankWaves * 64), 0, s,
+                       pr, maxnormB_sq, nsplits, part, lists, j1, j2, k1, k2);
+}
+
+}  // namespace vsm

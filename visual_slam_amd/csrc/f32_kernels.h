@@ -16,7 +16,7 @@ namespace vsm {
 constexpr int kF32RowPad = 256;
 constexpr int kF32StripRows = 256;  // queries per workgroup (8 waves * 32)
 
-inline int f32_dimp(int dim) { return dim <= 64 ? 64 : dim <= 128 ? 128 : 256; }
+__host__ __device__ inline int f32_dimp(int dim) { return dim <= 64 ? 64 : dim <= 128 ? 128 : 256; }
 
 struct F32Problem {
     const float* fragA;  // queries
@@ -37,5 +37,43 @@ void launch_f32_transform(const float* src, int n, int n_pad, int dim, bool dim_
 // Train side (optional): cidx/ck, nB entries.
 void launch_f32_knn(const F32Problem& pr, int32_t* j1, int32_t* j2, float* k1, float* k2,
                     int32_t* cidx, float* ck, void* scratch, hipStream_t s);
+
+// ---- bf16 coarse pass + exact re-rank (bf16_kernels.hip) -------------------------------
+// bf16 shadow of a float set: 32-row tiles of dimp/16 k-steps x 64 lanes x 8 bf16 (round to
+// nearest even), lane h*32 + r holding k = 16 s + 8 h .. + 7 of row r: the operand order of
+// v_mfma_f32_32x32x16_bf16.  maxnorm_sq = the largest squared row norm of the set.
+constexpr int kCoarseCap = 128;  // survivors one (split, query, lane half) list can hold
+
+// One allocation per set: [bf16 rows][256 B holding maxnorm_sq][init_l2: n_pad + 64 floats]
+// [init_dot: n_pad + 64 floats].  The init arrays are the accumulator start values of the coarse
+// kernel: -|b|^2 / 2 resp. 0 for real rows, -inf for padding rows.
+struct Bf16Shadow {
+    const unsigned short* rows;
+    const float* maxnorm_sq;
+    const float* init_l2;
+    const float* init_dot;
+};
+inline size_t bf16_rows_bytes(int n_pad, int dim) { return (size_t)n_pad * f32_dimp(dim) * 2; }
+inline size_t bf16_shadow_bytes(int n_pad, int dim)
+{
+    return bf16_rows_bytes(n_pad, dim) + 256 + 2 * ((size_t)n_pad + 64) * sizeof(float);
+}
+inline Bf16Shadow bf16_shadow_view(const void* base, int n_pad, int dim)
+{
+    const char* p = static_cast<const char*>(base);
+    Bf16Shadow v;
+    v.rows = reinterpret_cast<const unsigned short*>(p);
+    v.maxnorm_sq = reinterpret_cast<const float*>(p + bf16_rows_bytes(n_pad, dim));
+    v.init_l2 = v.maxnorm_sq + 64;
+    v.init_dot = v.init_l2 + n_pad + 64;
+    return v;
+}
+void launch_bf16_transform(const float* src, int n, int n_pad, int dim, bool dim_major, void* shadow_base,
+                           const float* nrm, hipStream_t s);
+size_t bf16_scratch_bytes(const F32Problem& pr);
+// Same outputs as the query side of launch_f32_knn, bit for bit, PROVIDED *overflow (device int)
+// reads 0 afterwards; a set flag means a survivor list was too short and the result is void.
+void launch_bf16_knn(const F32Problem& pr, const Bf16Shadow& shadowA, const Bf16Shadow& shadowB,
+                     int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow, hipStream_t s);
 
 }  // namespace vsm

@@ -295,7 +295,7 @@ static void launch_knn_t(const F32Problem& pr, int nstrips, int nsplits, int tps
     const int lds = 2 * 32 * DIMP * 4 + 512;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(f32_knn_kernel<DIMP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f32_knn_kernel<DIMP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }

@@ -73,6 +73,8 @@ struct DescSet {
     int n = 0, n_pad = 0, dim = 0;
     void* frag = nullptr;  // u8: fragment-major int8; f32: fragment-major float
     void* nrm = nullptr;   // u8: int32 nrm8; f32: float squared norms
+    void* shadow = nullptr;  // f32 only: bf16 operand-order copy + constants of the coarse pass
+    Bf16Shadow shadow_view() const { return bf16_shadow_view(shadow, n_pad, dim); }
 };
 
 }  // namespace
@@ -85,7 +87,9 @@ struct vsm_ctx {
     // workspace (grow-only)
     DevBuf d_pairs, d_items, d_rr1, d_rrj, d_rr2, d_colpart, d_cand;
     DevBuf d_slot0, d_slot1, d_slotd, d_counts, d_offsets, d_tight0, d_tight1;
-    DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage;
+    DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_flag;
+    // float sets: 0 = bf16 coarse pass + exact re-rank (exact kernel when a survivor list overflows), 1 = exact kernel only
+    int f32_mode = 0, last_f32_path = -1;
     HostBuf h_pairs, h_items, h_small;
     // last device-resident result
     int last_npairs = 0;
@@ -360,11 +364,12 @@ extern "C" void vsm_destroy(vsm_ctx* c)
     for (auto& s : c->sets) {
         if (s.frag) (void)hipFree(s.frag);
         if (s.nrm) (void)hipFree(s.nrm);
+        if (s.shadow) (void)hipFree(s.shadow);
     }
     DevBuf* bufs[] = {&c->d_pairs, &c->d_items, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart, &c->d_cand,
                       &c->d_slot0, &c->d_slot1, &c->d_slotd, &c->d_counts, &c->d_offsets,
                       &c->d_tight0, &c->d_tight1, &c->d_dense0, &c->d_dense1,
-                      &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage};
+                      &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage, &c->d_coarse, &c->d_flag};
     for (DevBuf* b : bufs) b->release();
     c->h_pairs.release();
     c->h_items.release();
@@ -485,6 +490,12 @@ static int upload_f32_common(vsm_ctx* c, const void* src, int n, int dim, int la
             (void)hipFree(s.frag);
             return fail(c, VSM_ENOMEM, "hipMalloc(norms): %s", hipGetErrorString(e));
         }
+        e = hipMalloc(&s.shadow, bf16_shadow_bytes(s.n_pad, dim));
+        if (e != hipSuccess) {
+            (void)hipFree(s.frag);
+            (void)hipFree(s.nrm);
+            return fail(c, VSM_ENOMEM, "hipMalloc(bf16 shadow): %s", hipGetErrorString(e));
+        }
         const float* dsrc = static_cast<const float*>(src);
         if (!src_on_device) {
             e = c->d_stage.ensure((size_t)n * dim * sizeof(float));
@@ -493,16 +504,20 @@ static int upload_f32_common(vsm_ctx* c, const void* src, int n, int dim, int la
             if (e != hipSuccess) {
                 (void)hipFree(s.frag);
                 (void)hipFree(s.nrm);
+                (void)hipFree(s.shadow);
                 return fail(c, VSM_ENODEV, "staging copy: %s", hipGetErrorString(e));
             }
             dsrc = c->d_stage.as<float>();
         }
         launch_f32_transform(dsrc, n, s.n_pad, dim, layout == VSM_LAYOUT_DIM_MAJOR,
                              static_cast<float*>(s.frag), static_cast<float*>(s.nrm), c->stream);
+        launch_bf16_transform(dsrc, n, s.n_pad, dim, layout == VSM_LAYOUT_DIM_MAJOR, s.shadow,
+                              static_cast<const float*>(s.nrm), c->stream);
         e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) {
             (void)hipFree(s.frag);
             (void)hipFree(s.nrm);
+            (void)hipFree(s.shadow);
             return fail(c, VSM_ENODEV, "descriptor transform: %s", hipGetErrorString(e));
         }
     }
@@ -529,6 +544,7 @@ extern "C" int vsm_release_set(vsm_ctx* c, int set)
     DescSet& s = c->sets[set];
     if (s.frag) (void)hipFree(s.frag);
     if (s.nrm) (void)hipFree(s.nrm);
+    if (s.shadow) (void)hipFree(s.shadow);
     s = DescSet();
     return VSM_OK;
 }
@@ -564,8 +580,6 @@ int run_f32_knn(vsm_ctx* c, const DescSet* A, const DescSet* B, int metric, bool
     r->k2 = c->d_knn2.as<float>();
     r->cidx = c->d_dense1.as<int32_t>();
     r->ck = c->d_rr1.as<float>();
-    c->ev_valid = false;
-    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     F32Problem pr;
     pr.fragA = static_cast<const float*>(A->frag);
     pr.nrmA = static_cast<const float*>(A->nrm);
@@ -574,6 +588,42 @@ int run_f32_knn(vsm_ctx* c, const DescSet* A, const DescSet* B, int metric, bool
     pr.nA = A->n; pr.nB = B->n; pr.nA_pad = A->n_pad; pr.nB_pad = B->n_pad;
     pr.dim = A->dim;
     pr.metric = metric;
+    c->ev_valid = false;
+    if (c->f32_mode == 0) {
+        // bf16 coarse pass + exact re-rank; the train side of a mutual check is the same search
+        // with the roles swapped (its runner-up outputs land in spare buffers)
+        F32Problem sw = pr;
+        sw.fragA = pr.fragB; sw.nrmA = pr.nrmB; sw.fragB = pr.fragA; sw.nrmB = pr.nrmA;
+        sw.nA = pr.nB; sw.nB = pr.nA; sw.nA_pad = pr.nB_pad; sw.nB_pad = pr.nA_pad;
+        size_t need = bf16_scratch_bytes(pr);
+        if (want_col) need = std::max(need, bf16_scratch_bytes(sw));
+        HIPCHK(c, c->d_coarse.ensure(need));
+        HIPCHK(c, c->d_flag.ensure(256));
+        HIPCHK(c, c->h_small.ensure(64));
+        if (want_col) {
+            HIPCHK(c, c->d_slot1.ensure(nb * 4));
+            HIPCHK(c, c->d_slotd.ensure(nb * 4));
+        }
+        if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_flag.p, 0, sizeof(int), c->stream));
+        launch_bf16_knn(pr, A->shadow_view(), B->shadow_view(), r->j1, r->j2, r->k1, r->k2, c->d_coarse.p,
+                        c->d_flag.as<int>(), c->stream);
+        if (want_col)
+            launch_bf16_knn(sw, B->shadow_view(), A->shadow_view(), r->cidx, c->d_slot1.as<int32_t>(), r->ck,
+                            c->d_slotd.as<float>(), c->d_coarse.p, c->d_flag.as<int>(), c->stream);
+        if (c->timing) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        int* flag = c->h_small.as<int>();
+        HIPCHK(c, hipMemcpyAsync(flag, c->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        if (*flag == 0) {
+            c->ev_valid = c->timing != 0;
+            c->last_f32_path = 0;
+            return VSM_OK;
+        }
+        // a survivor list overflowed (heavily tied or adversarially ordered scores): exact kernel
+    }
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     HIPCHK(c, c->d_colpart.ensure(f32_scratch_bytes(pr, want_col)));
     launch_f32_knn(pr, r->j1, r->j2, r->k1, r->k2, want_col ? r->cidx : nullptr, want_col ? r->ck : nullptr,
                    c->d_colpart.p, c->stream);
@@ -582,6 +632,7 @@ int run_f32_knn(vsm_ctx* c, const DescSet* A, const DescSet* B, int metric, bool
         c->ev_valid = true;
     }
     HIPCHK(c, hipGetLastError());
+    c->last_f32_path = 1;
     return VSM_OK;
 }
 
@@ -839,6 +890,16 @@ extern "C" int vsm_knn2(vsm_ctx* c, int set_q, int set_db, int metric,
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return A->n;
 }
+
+extern "C" int vsm_set_f32_mode(vsm_ctx* c, int mode)
+{
+    if (!c) return VSM_EINVAL;
+    if (mode != VSM_F32_FAST_EXACT && mode != VSM_F32_MFMA_F32) return fail(c, VSM_EINVAL, "unknown f32 mode %d", mode);
+    c->f32_mode = mode;
+    return VSM_OK;
+}
+
+extern "C" int vsm_last_f32_path(const vsm_ctx* c) { return c ? c->last_f32_path : VSM_EINVAL; }
 
 extern "C" int vsm_merge_top2_f32(const float* k1, const float* k2, const int32_t* i1, const int32_t* i2,
                                   const int64_t* base, int nslices, int nq, int metric,
