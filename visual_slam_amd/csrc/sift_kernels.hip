@@ -122,14 +122,14 @@ __device__ __forceinline__ int xcd_contiguous_item(int bid, int nb)
 
 // one step's LDS-DMA: 32 KiB of operand-order descriptors (4 KiB per wave) + 256 packed norms.
 // frag_src / nrm_src already include this wave's and lane's offsets.
+template <int NWAVES>
 __device__ __forceinline__ void stage_step(char* smem, int buf, const int8_t* frag_src, const int32_t* nrm_src,
                                            int wave)
 {
-    char* dst = smem + buf * kLdsTile + wave * 4096;
-    dma16(frag_src, dst);
-    dma16(frag_src + 1024, dst + 1024);
-    dma16(frag_src + 2048, dst + 2048);
-    dma16(frag_src + 3072, dst + 3072);
+    constexpr int kPieces = kLdsTile / 1024 / NWAVES;   // 1 KiB LDS-DMA pieces per wave
+    char* dst = smem + buf * kLdsTile + wave * (kPieces * 1024);
+#pragma unroll
+    for (int p = 0; p < kPieces; ++p) dma16(frag_src + p * 1024, dst + p * 1024);
     if (wave < 4) dma4(nrm_src, smem + 2 * kLdsTile + buf * kLdsNorm + wave * 256);
 }
 
@@ -162,11 +162,13 @@ __device__ __forceinline__ void tile_consts(const int* nl_tile, int half, int (&
 }
 
 // ---- 1. query pass ------------------------------------------------------------------
-// Each wave owns kQueryRB blocks of 32 query rows; they share every streamed operand and norm
-// read, which halves the LDS traffic per MFMA.
-constexpr int kQueryRB = kStripRows / 256;
+// A workgroup is kQueryWaves waves; each wave owns kQueryRB blocks of 32 query rows, which share
+// every streamed operand and norm read (a quarter of the LDS traffic per MFMA of one block per
+// wave).  Two workgroups fit a CU, so one computes while the other waits at its step barrier.
+constexpr int kQueryWaves = 4;
+constexpr int kQueryRB = kStripRows / (32 * kQueryWaves);
 
-__global__ __launch_bounds__(512, 4)
+__global__ __launch_bounds__(kQueryWaves * 64, 2)
 void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ items,
                        int32_t* __restrict__ rr_d1, int32_t* __restrict__ rr_j1,
                        int32_t* __restrict__ rr_d2, int negscale)
@@ -195,7 +197,7 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
         for (int s = 0; s < 4; ++s) pf[rb][s] = *reinterpret_cast<const v4i*>(src + s * 1024);
     }
 
-    const int8_t* Bsrc = pw.fragB + (size_t)(c0 >> 5) * kTileBytes + wave * 4096 + lane * 16;
+    const int8_t* Bsrc = pw.fragB + (size_t)(c0 >> 5) * kTileBytes + wave * (kLdsTile / kQueryWaves) + lane * 16;
     const int32_t* Nsrc = pw.nrmB + c0 + (wave & 3) * 64 + lane;
 
     // unpacked running result per query row
@@ -203,13 +205,13 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
 #pragma unroll
     for (int rb = 0; rb < kQueryRB; ++rb) { bestd[rb] = kDistPad; bestcol[rb] = INT32_MAX; second[rb] = kDistPad; }
 
-    stage_step(smem, 0, Bsrc, Nsrc, wave);
+    stage_step<kQueryWaves>(smem, 0, Bsrc, Nsrc, wave);
     __syncthreads();
 
     for (int st = 0; st < nsteps; ++st) {
         const int cur = st & 1;
         if (st + 1 < nsteps)
-            stage_step(smem, cur ^ 1, Bsrc + (size_t)(st + 1) * kLdsTile, Nsrc + (st + 1) * kStepRows, wave);
+            stage_step<kQueryWaves>(smem, cur ^ 1, Bsrc + (size_t)(st + 1) * kLdsTile, Nsrc + (st + 1) * kStepRows, wave);
         const char* Bt = smem + cur * kLdsTile + lane * 16;
         const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm);
 
@@ -302,7 +304,7 @@ void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsStream);
         attr_set = true;
     }
-    hipLaunchKernelGGL(sift_query_kernel, dim3(nitems), dim3(512), kLdsStream, s,
+    hipLaunchKernelGGL(sift_query_kernel, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
                        pairs, items, rr_d1, rr_j1, rr_d2, -512);
 }
 
@@ -342,13 +344,13 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
 
     int bestd = kDistPad, bestrow = INT32_MAX;
 
-    stage_step(smem, 0, Asrc, Nsrc, wave);
+    stage_step<8>(smem, 0, Asrc, Nsrc, wave);
     __syncthreads();
 
     for (int st = 0; st < nsteps; ++st) {
         const int cur = st & 1;
         if (st + 1 < nsteps)
-            stage_step(smem, cur ^ 1, Asrc + (size_t)(st + 1) * kLdsTile, Nsrc + (st + 1) * kStepRows, wave);
+            stage_step<8>(smem, cur ^ 1, Asrc + (size_t)(st + 1) * kLdsTile, Nsrc + (st + 1) * kStepRows, wave);
         const char* At = smem + cur * kLdsTile + lane * 16;
         const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm);
         int m = INT32_MAX;
