@@ -28,6 +28,18 @@ F32_MFMA_PEAK_TFLOPS = 157.3    # f32-input MFMA (exact f32), = vector peak
 BF16_DENSE_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed hardware-counter passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE over tools/traffic_probe.py at this workload's shape, folded by
+    tools/pmc_summary.py); None when no such pass is in the tree."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic_sift_exhaustive.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def f32_roofline(m, flops, kms):
     """Roofline object of a float-descriptor search: priced against the matrix-core peak of the
     path that actually ran (bf16 coarse pass + exact re-rank, or the f32-input kernel)."""
@@ -204,7 +216,12 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
                    "pairs_total": int(len(pairs_all)), "parallelism": "pair list sharded x%d" % world,
                    "matches_per_pair": nmatch / max(npairs, 1)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
-                     "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": None,
+                     "frac": achieved / INT8_DENSE_PEAK_TOPS,
+                     "traffic": measured_traffic("vsm::sift_query_kernel")
+                     if (nimg, nfeat, pps) == (1000, 8192, 2048) else None,
+                     "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes "
+                                     "(profiles/r01_probe1000_pmc_*.csv; FETCH_SIZE doubled as gfx950 needs); "
+                                     "algorithmic operand bytes per launch: %d" % (pps * 2 * nfeat * 128),
                      "kernel": "sift_query_kernel", "kernel_ms": kms,
                      "verify_kernel_ms": float(np.mean(verify_ms)),
                      "note": "int8 ops: 256 per descriptor pair (128 MAC), one direction counted once"},

@@ -185,6 +185,10 @@ int vsm_mat_write_pmatch(const char* image1, const char* image2, int fc1, int fc
 /* MatchFile(image).GetPMatch(other, FC, NM, matches) (MatchFile.cpp:856-895). */
 int vsm_mat_get_pmatch(const char* image, const char* other, int fc_other,
                        int32_t* idx_this, int32_t* idx_other, int cap);
+/* MatchFile(image).GetPMatchR (MatchFile.cpp:897-936): the same record with the two rows
+ * exchanged: row0 = indices in `other`, row1 = indices in `image`. */
+int vsm_mat_get_pmatch_r(const char* image, const char* other, int fc_other,
+                         int32_t* row0, int32_t* row1, int cap);
 /* MatchFile::GetMatchCount (MatchFile.cpp:938-958). Returns 1/0. */
 int vsm_mat_get_match_count(const char* image, const char* other, int* nm, int* nf);
 

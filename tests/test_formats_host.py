@@ -165,6 +165,10 @@ def test_mat_bytes_match_oracle(tmp_path):
     np.testing.assert_array_equal(ob, ia)
     assert host.get_match_count(str(d1 / str(a)), str(d1 / str(b))) == (33, 0)
     assert host.get_match_count(str(d1 / "0"), str(d1 / "9")) is None
+    ra, rb = host.get_pmatch_r(str(d1 / str(a)), str(d1 / str(b)), fc[b])   # rows exchanged
+    pa, pb = host.get_pmatch(str(d1 / str(a)), str(d1 / str(b)), fc[b])
+    np.testing.assert_array_equal(ra, pb)
+    np.testing.assert_array_equal(rb, pa)
     assert len(host.get_pmatch(str(d1 / str(a)), str(d1 / str(b)), fc[b] + 1)[0]) == 0
 
 

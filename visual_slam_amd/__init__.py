@@ -30,6 +30,7 @@ from .host import (  # noqa: F401
     write_sift,
     write_pmatch,
     get_pmatch,
+    get_pmatch_r,
     get_match_count,
     nearest_embed,
     mutual_nn_match,
@@ -41,6 +42,6 @@ __all__ = [
     "F32_FAST_EXACT", "F32_MFMA_F32",
     "generate_imagePairs", "generate_exhaustive_pairs", "get_list_matching_pairs",
     "save_matching_sfm", "save_feature_locations", "read_feature_locations",
-    "read_sift", "write_sift", "write_pmatch", "get_pmatch", "get_match_count",
+    "read_sift", "write_sift", "write_pmatch", "get_pmatch", "get_pmatch_r", "get_match_count",
     "nearest_embed", "mutual_nn_match",
 ]

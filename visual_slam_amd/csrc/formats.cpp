@@ -654,6 +654,13 @@ extern "C" int vsm_mat_get_pmatch(const char* image, const char* other, int fc_o
     return nm;
 }
 
+extern "C" int vsm_mat_get_pmatch_r(const char* image, const char* other, int fc_other,
+                                    int32_t* row0, int32_t* row1, int cap)
+{
+    // MatchFile.cpp:897-936: the same record, first stored row into matches[1], second into matches[0]
+    return vsm_mat_get_pmatch(image, other, fc_other, row1, row0, cap);
+}
+
 extern "C" int vsm_mat_get_match_count(const char* image, const char* other, int* nm, int* nf)
 {
     if (nm) *nm = 0;

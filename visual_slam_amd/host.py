@@ -134,6 +134,12 @@ def get_pmatch(image, other, fc_other):
     return a[:nm], b[:nm]
 
 
+def get_pmatch_r(image, other, fc_other):
+    """GetPMatchR (MatchFile.cpp:897-936): (indices in `other`, indices in `image`)."""
+    a, b = get_pmatch(image, other, fc_other)
+    return b, a
+
+
 def get_match_count(image, other):
     nm, nf = C.c_int(0), C.c_int(0)
     ok = B.lib().vsm_mat_get_match_count(_b(image), _b(other), C.byref(nm), C.byref(nf))
