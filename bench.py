@@ -80,11 +80,27 @@ def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the multi-rank path on a one-GPU box: VSM_BENCH_REHEARSAL=1 puts every rank on
+    # device 0 and runs the collectives over gloo on host tensors (RCCL refuses two ranks per GPU).
+    global REHEARSAL
+    REHEARSAL = os.environ.get("VSM_BENCH_REHEARSAL", "") == "1"
+    if REHEARSAL:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if REHEARSAL:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     return torch, dist, world, rank, local
+
+
+REHEARSAL = False
+
+
+def comm_device():
+    return "cpu" if REHEARSAL else "cuda"
 
 
 def barrier_sync(torch, dist, world):
@@ -97,7 +113,7 @@ def barrier_sync(torch, dist, world):
 def max_over_ranks(torch, dist, world, seconds):
     if world == 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+    t = torch.tensor([seconds], dtype=torch.float64, device=comm_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -105,7 +121,7 @@ def max_over_ranks(torch, dist, world, seconds):
 def sum_over_ranks(torch, dist, world, v):
     if world == 1:
         return v
-    t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
+    t = torch.tensor([float(v)], dtype=torch.float64, device=comm_device())
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
@@ -226,7 +242,7 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
                      "verify_kernel_ms": float(np.mean(verify_ms)),
                      "note": "int8 ops: 256 per descriptor pair (128 MAC), one direction counted once"},
     }
-    if rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         sets = [arena[i].cpu().numpy() for i in range(min(8, nimg))]
         out["cpu_baseline"] = cpu_baseline_u8(sets, args.cpu_seconds)
     m.close()
@@ -270,7 +286,7 @@ def run_superpoint_pair(args, torch, dist, world, rank):
                    "parallelism": "replicas x%d" % world, "matches": int((m0 >= 0).sum())},
         "roofline": f32_roofline(m, OPS_PER_EVAL_F32 * float(n) * n, kms),
     }
-    if rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         import oracle_lib as orc
         threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0")) or 16, os.cpu_count() or 1))
         rows = 1024
@@ -324,7 +340,7 @@ def run_sift_large_pair(args, torch, dist, world, rank):
                      "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": None,
                      "kernel": "sift_query_kernel", "kernel_ms": kms},
     }
-    if rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         sets = [arena[i, :8192].cpu().numpy() for i in range(2)]
         out["cpu_baseline"] = cpu_baseline_u8(sets, args.cpu_seconds)
     m.close()
@@ -360,7 +376,7 @@ def run_db_query(args, torch, dist, world, rank):
         i1, i2, k1, k2 = m.knn2(sq, sdb, vsm.METRIC_L2, want_idx2=True)
         if world == 1:
             return B.merge_top2_f32(k1[None], k2[None], i1[None], i2[None], base, vsm.METRIC_L2)
-        pack = torch.from_numpy(np.stack([k1.view(np.int32), k2.view(np.int32), i1, i2])).cuda()
+        pack = torch.from_numpy(np.stack([k1.view(np.int32), k2.view(np.int32), i1, i2])).to(comm_device())
         allp = [torch.empty_like(pack) for _ in range(world)]
         dist.all_gather(allp, pack)
         allp = torch.stack(allp).cpu().numpy()
