@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sift_exhaustive",
-                    choices=["sift_exhaustive", "superpoint_pair", "sift_large_pair", "db_query"])
+                    choices=["sift_exhaustive", "superpoint_pair", "superpoint_pairs", "sift_large_pair", "db_query"])
     ap.add_argument("--images", type=int, default=1000)
     ap.add_argument("--features", type=int, default=8192)
     ap.add_argument("--pairs-per-step", type=int, default=2048)
@@ -299,6 +299,69 @@ def run_superpoint_pair(args, torch, dist, world, rank):
     return out
 
 
+def run_superpoint_pairs(args, torch, dist, world, rank):
+    """Exhaustive mutual-NN matching of 64 images x 4096 SuperPoint-256 float descriptors, 256 pairs per
+    submission (the float counterpart of the SIFT pair-list workload)."""
+    import visual_slam_amd as vsm
+
+    nimg, n, pps = 64, 4096, 256
+    g = torch.Generator(device="cuda")
+    g.manual_seed(555)
+    pool = torch.randn((n, 256), generator=g, device="cuda")
+    ids = []
+    m = vsm.Matcher(torch.cuda.current_device())
+    for i in range(nimg):
+        x = torch.randn((n, 256), generator=g, device="cuda")
+        k = n // 4
+        dst = torch.randperm(n, generator=g, device="cuda")[:k]
+        src = torch.randperm(n, generator=g, device="cuda")[:k]
+        x[dst] = pool[src] + 0.05 * torch.randn((k, 256), generator=g, device="cuda")
+        x /= x.norm(dim=1, keepdim=True)
+        torch.cuda.synchronize()
+        ids.append(m.upload_f32_device(x.data_ptr(), n, 256))
+    m.set_timing(True)
+    m.set_f32_mode(args.f32_mode)
+    pairs_all = vsm.generate_exhaustive_pairs(nimg)
+    per = (len(pairs_all) + world - 1) // world
+    mine = pairs_all[rank * per:(rank + 1) * per]
+    idmap = np.asarray(ids, np.int32)
+
+    def step(k):
+        lo = (k * pps) % max(len(mine) - pps + 1, 1)
+        pr = idmap[np.asarray(mine[lo:lo + pps], np.int64)]
+        tot = m.match_pairs_device(pr, ratio=None, mutual=True, metric=vsm.METRIC_DOT, min_score=0.5)
+        m.fetch_matches(len(pr), tot)
+        return len(pr), tot
+
+    for k in range(args.warmup):
+        step(k)
+    barrier_sync(torch, dist, world)
+    t0 = time.perf_counter()
+    kernel_ms, npairs, nmatch = [], 0, 0
+    for k in range(args.steps):
+        a, b = step(args.warmup + k)
+        npairs += a
+        nmatch += b
+        kernel_ms.append(m.last_kernel_ms())
+    barrier_sync(torch, dist, world)
+    dt = max_over_ranks(torch, dist, world, time.perf_counter() - t0)
+    total_pairs = sum_over_ranks(torch, dist, world, npairs)
+    kms = float(np.mean(kernel_ms))
+    out = {
+        "metric": "descriptor distance evals/sec", "value": total_pairs * float(n) * n / dt / 1e9, "unit": "G/s",
+        "pairs_per_s": total_pairs / dt,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "exhaustive SuperPoint-256 f32 matching, %d images x %d keypoints, mutual-NN, "
+                               "%d pairs per step per GPU, match lists copied to host" % (nimg, n, pps),
+                   "parallelism": "pair list sharded x%d" % world, "matches_per_pair": nmatch / max(npairs, 1)},
+        "roofline": f32_roofline(m, OPS_PER_EVAL_F32 * float(pps) * n * n, kms),
+    }
+    m.close()
+    return out
+
+
 def run_sift_large_pair(args, torch, dist, world, rank):
     """One pair of 65536 x 65536 SIFT-128 descriptors per step."""
     import visual_slam_amd as vsm
@@ -413,6 +476,7 @@ def main():
     args = parse()
     torch, dist, world, rank, local = dist_setup(args)
     fn = {"sift_exhaustive": run_sift_exhaustive, "superpoint_pair": run_superpoint_pair,
+          "superpoint_pairs": run_superpoint_pairs,
           "sift_large_pair": run_sift_large_pair, "db_query": run_db_query}[args.workload]
     out = fn(args, torch, dist, world, rank)
     if rank == 0:

@@ -201,3 +201,35 @@ def test_survivor_overflow_falls_back(matcher, f32_mode):
     b2 = (t * a[0] + (1 - t) * a[1]).astype(np.float32)
     _knn_check(matcher, a, b2, vsm.METRIC_DOT)
     assert matcher.last_f32_path() == vsm.F32_MFMA_F32
+
+
+@pytest.mark.parametrize("metric,ratio,mutual", [(vsm.METRIC_DOT, None, True), (vsm.METRIC_L2, 0.8, True),
+                                                 (vsm.METRIC_L2, 0.9, False)])
+def test_float_pairs_in_one_submission(matcher, metric, ratio, mutual):
+    """Many float pairs per call (ragged sizes, an empty set, a one-row set) against the oracle pair by pair."""
+    rng = np.random.default_rng(41)
+    sizes = [700, 513, 0, 900, 1, 1100, 256]
+    pool = synth.unit_f32(600, 256, rng)
+    imgs = []
+    for n in sizes:
+        d = synth.unit_f32(max(n, 1), 256, rng)[:n]
+        k = min(n, 600) // 2
+        if k:
+            noisy = pool[rng.choice(600, k, replace=False)] + 0.05 * rng.standard_normal((k, 256)).astype(np.float32)
+            d[rng.choice(n, k, replace=False)] = noisy / np.linalg.norm(noisy, axis=1, keepdims=True)
+        imgs.append(np.ascontiguousarray(d, np.float32))
+    ids = [matcher.upload_f32(d) for d in imgs]
+    pairs = [(a, b) for a in range(len(sizes)) for b in range(len(sizes)) if a != b][:30]
+    pr = np.asarray([[ids[a], ids[b]] for a, b in pairs], np.int32)
+    off, i0, i1 = matcher.match_pairs(pr, ratio=ratio, mutual=mutual, metric=metric, min_score=0.5)
+    fr = None if ratio is None else tuple(B.ratio_to_fraction(ratio))
+    total = 0
+    for k, (a, b) in enumerate(pairs):
+        o0, _, _, _ = orc.match_dense_f32(imgs[a], imgs[b], metric, orc.params(fr, mutual, min_score=0.5))
+        want0 = np.nonzero(o0 >= 0)[0]
+        np.testing.assert_array_equal(i0[off[k]:off[k + 1]], want0)
+        np.testing.assert_array_equal(i1[off[k]:off[k + 1]], o0[want0])
+        total += len(want0)
+    assert off[-1] == total and total > 500
+    for sid in ids:
+        matcher.release(sid)

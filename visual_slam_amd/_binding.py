@@ -216,22 +216,25 @@ class Matcher:
         self._check(self._l.vsm_match_pair_dense(self._h, set0, set1, C.byref(p), metric, _ptr(m0), _ptr(m1)))
         return m0[:n0].copy(), m1[:n1].copy()
 
-    def match_pairs(self, pairs, ratio=0.8, mutual=True, max_dist_sq=-1, cap=None):
+    def match_pairs(self, pairs, ratio=0.8, mutual=True, max_dist_sq=-1, cap=None, metric=METRIC_L2,
+                    min_score=float("-inf"), max_dist_sq_f=-1.0):
+        """Many pairs per submission; u8 pairs or float pairs (one padded dimension per call)."""
         pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
-        p = make_params(ratio, mutual, max_dist_sq)
+        p = make_params(ratio, mutual, max_dist_sq, min_score, max_dist_sq_f)
         if cap is None:
             cap = int(sum(self._kinds[int(a)][1] for a in pairs[:, 0])) or 1
         off = np.empty(len(pairs) + 1, np.int64)
         idx0 = np.empty(cap, np.int32)
         idx1 = np.empty(cap, np.int32)
-        tot = self._check(self._l.vsm_match_pairs(self._h, _ptr(pairs), len(pairs), C.byref(p), METRIC_L2,
+        tot = self._check(self._l.vsm_match_pairs(self._h, _ptr(pairs), len(pairs), C.byref(p), metric,
                                                   _ptr(off), _ptr(idx0), _ptr(idx1), cap))
         return off, idx0[:tot].copy(), idx1[:tot].copy()
 
-    def match_pairs_device(self, pairs, ratio=0.8, mutual=True, max_dist_sq=-1):
+    def match_pairs_device(self, pairs, ratio=0.8, mutual=True, max_dist_sq=-1, metric=METRIC_L2,
+                           min_score=float("-inf"), max_dist_sq_f=-1.0):
         pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
-        p = make_params(ratio, mutual, max_dist_sq)
-        return self._check(self._l.vsm_match_pairs_device(self._h, _ptr(pairs), len(pairs), C.byref(p), METRIC_L2))
+        p = make_params(ratio, mutual, max_dist_sq, min_score, max_dist_sq_f)
+        return self._check(self._l.vsm_match_pairs_device(self._h, _ptr(pairs), len(pairs), C.byref(p), metric))
 
     def fetch_matches(self, npairs, total):
         off = np.empty(npairs + 1, np.int64)

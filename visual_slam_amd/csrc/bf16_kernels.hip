@@ -128,12 +128,23 @@ static_assert(kF32RowPad % kCoarseStripRows == 0, "query strips must tile the pa
 // coarse key is then dot - |b|^2 / 2, half the exact key), 0 for the dot ranking, and -inf for the
 // padding rows past the end of the set, which therefore never rank.  The kernel itself is the same
 // for both rankings.
+// index of the problem whose block range holds block L (first-block offsets ascending)
+template <class GetFirst>
+__device__ __forceinline__ int find_problem(int nprobs, int L, GetFirst first)
+{
+    int lo = 0, hi = nprobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first(mid) <= L) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
 template <int DIMP>
 __global__ __launch_bounds__(kCoarseWaves * 64, 2)
-void bf16_coarse_kernel(F32Problem pr, const unsigned short* __restrict__ bfA, const unsigned short* __restrict__ bfB,
-                        const float* __restrict__ initB, const float* __restrict__ maxnormB_sq, int nstrips,
-                        int tiles_per_split, CoarsePart* __restrict__ part, uint2* __restrict__ lists,
-                        int* __restrict__ overflow)
+void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
+                        CoarsePart* __restrict__ part_all, uint2* __restrict__ lists_all, int* __restrict__ overflow)
 {
     constexpr int S = DIMP / 16;             // k-steps (MFMAs) per tile
     constexpr int RB = kCoarseRB;
@@ -149,14 +160,24 @@ void bf16_coarse_kernel(F32Problem pr, const unsigned short* __restrict__ bfA, c
     const int nb = gridDim.x, bid = blockIdx.x;
     const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
     const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int split = L / nstrips, strip = L % nstrips;
+    const int pi = find_problem(nprobs, L, [&](int i) { return probs[i].blk0; });
+    const CoarseProblem& P = probs[pi];
+    const F32Problem pr = P.pr;
+    const unsigned short* __restrict__ bfA = P.bfA;
+    const unsigned short* __restrict__ bfB = P.bfB;
+    const float* __restrict__ initB = P.initB;
+    const int nstrips = P.nstrips, tiles_per_split = P.tiles_per_split;
+    CoarsePart* __restrict__ part = part_all + P.part_off;
+    uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
+    const int Lp = L - P.blk0;
+    const int split = Lp / nstrips, strip = Lp % nstrips;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane5 = lane & 31, half = lane >> 5;
     const bool l2 = pr.metric == 1;
-    const float maxnb = *maxnormB_sq;
+    const float maxnb = *P.maxnormB_sq;
 
     // persistent operands: this wave's RB x 32 queries
     v8bf qf[RB][S];
@@ -323,15 +344,26 @@ __device__ __forceinline__ float exact_dot(const float* fragA, const float* frag
 }
 
 __global__ __launch_bounds__(kRerankWaves * 64)
-void bf16_rerank_kernel(F32Problem pr, const float* __restrict__ maxnormB_sq, int nsplits,
-                        const CoarsePart* __restrict__ part, const uint2* __restrict__ lists,
-                        int32_t* __restrict__ j1, int32_t* __restrict__ j2,
-                        float* __restrict__ k1, float* __restrict__ k2)
+void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
+                        const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
+                        int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
+                        float* __restrict__ k1_all, float* __restrict__ k2_all)
 {
     __shared__ int s_rows[kRerankWaves][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * kRerankWaves + wave;
+    const int pi = find_problem(nprobs, (int)blockIdx.x, [&](int i) { return probs[i].rr_blk0; });
+    const CoarseProblem& P = probs[pi];
+    const F32Problem pr = P.pr;
+    const int nsplits = P.nsplits;
+    const float* maxnormB_sq = P.maxnormB_sq;
+    const CoarsePart* __restrict__ part = part_all + P.part_off;
+    const uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
+    int32_t* __restrict__ j1 = j1_all + P.out_off;
+    int32_t* __restrict__ j2 = j2_all + P.out_off;
+    float* __restrict__ k1 = k1_all + P.out_off;
+    float* __restrict__ k2 = k2_all + P.out_off;
+    const int i = ((int)blockIdx.x - P.rr_blk0) * kRerankWaves + wave;
     if (i >= pr.nA) return;   // the whole wave leaves; no workgroup barrier below
     volatile int* rows = s_rows[wave];
     const bool l2 = pr.metric == 1;
@@ -425,33 +457,46 @@ void bf16_rerank_kernel(F32Problem pr, const float* __restrict__ maxnormB_sq, in
 }
 
 // ---------------------------------------------------------------------------------
-// launch
+// planning and launch
 // ---------------------------------------------------------------------------------
-static void coarse_geometry(const F32Problem& pr, int* nstrips, int* nsplits, int* tiles_per_split)
+CoarseTotals plan_coarse(CoarseProblem* probs, int n, int target_wgs)
 {
-    const int ntiles = pr.nB_pad / 32;
-    *nstrips = pr.nA_pad / kCoarseStripRows;
-    int want = (1024 + *nstrips - 1) / *nstrips;   // >= 1024 workgroups of 4 waves when the database allows
-    int tps = (ntiles + want - 1) / want;
-    tps = (tps + 7) & ~7;                          // whole LDS steps at every dimension
-    *tiles_per_split = tps;
-    *nsplits = (ntiles + tps - 1) / tps;
+    long long unsplit = 0;
+    for (int i = 0; i < n; ++i) unsplit += probs[i].pr.nA_pad / kCoarseStripRows;
+    // database splits per problem: only as many as it takes to fill the chip
+    const int want = unsplit >= target_wgs || unsplit == 0 ? 1 : (int)((target_wgs + unsplit - 1) / unsplit);
+    CoarseTotals t;
+    for (int i = 0; i < n; ++i) {
+        CoarseProblem& p = probs[i];
+        const int ntiles = p.pr.nB_pad / 32;
+        p.nstrips = p.pr.nA_pad / kCoarseStripRows;
+        int tps = (ntiles + want - 1) / want;
+        tps = std::max(8, (tps + 7) & ~7);            // whole LDS steps at every dimension
+        p.tiles_per_split = tps;
+        p.nsplits = std::max(1, (ntiles + tps - 1) / tps);
+        p.blk0 = t.coarse_blocks;
+        p.rr_blk0 = t.rerank_blocks;
+        p.reserved = 0;
+        p.part_off = t.sublists;
+        p.out_off = t.out_rows;
+        t.coarse_blocks += p.nstrips * p.nsplits;
+        t.rerank_blocks += (p.pr.nA + kRerankWaves - 1) / kRerankWaves;
+        t.sublists += (int64_t)p.nsplits * p.pr.nA_pad * 2;
+        t.out_rows += p.pr.nA_pad;
+    }
+    return t;
 }
 
-static size_t part_bytes(size_t per) { return (per * sizeof(CoarsePart) + 255) & ~(size_t)255; }
+static size_t part_bytes(int64_t sublists) { return ((size_t)sublists * sizeof(CoarsePart) + 255) & ~(size_t)255; }
 
-size_t bf16_scratch_bytes(const F32Problem& pr)
+size_t coarse_scratch_bytes(const CoarseTotals& t)
 {
-    int nstrips, nsplits, tps;
-    coarse_geometry(pr, &nstrips, &nsplits, &tps);
-    const size_t per = (size_t)nsplits * pr.nA_pad * 2;
-    return part_bytes(per) + per * kCoarseCap * sizeof(uint2);
+    return part_bytes(t.sublists) + (size_t)t.sublists * kCoarseCap * sizeof(uint2) + 256;
 }
 
 template <int DIMP>
-static void launch_coarse_t(const F32Problem& pr, const unsigned short* bfA, const unsigned short* bfB,
-                            const float* initB, const float* maxnormB_sq, int nstrips, int nsplits, int tps,
-                            CoarsePart* part, uint2* lists, int* overflow, hipStream_t s)
+static void launch_coarse_t(const CoarseProblem* d_probs, int nprobs, int blocks, CoarsePart* part, uint2* lists,
+                            int* overflow, hipStream_t s)
 {
     const int lds = 2 * kCoarseStepBytes;
     static bool attr_set = false;
@@ -460,28 +505,24 @@ static void launch_coarse_t(const F32Problem& pr, const unsigned short* bfA, con
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(bf16_coarse_kernel<DIMP>, dim3(nstrips * nsplits), dim3(kCoarseWaves * 64), lds, s,
-                       pr, bfA, bfB, initB, maxnormB_sq, nstrips, tps, part, lists, overflow);
+    hipLaunchKernelGGL(bf16_coarse_kernel<DIMP>, dim3(blocks), dim3(kCoarseWaves * 64), lds, s,
+                       d_probs, nprobs, part, lists, overflow);
 }
 
-void launch_bf16_knn(const F32Problem& pr, const Bf16Shadow& shA, const Bf16Shadow& shB,
-                     int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow, hipStream_t s)
+void launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
+                       int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow,
+                       hipStream_t s)
 {
-    const unsigned short* bfA = shA.rows;
-    const unsigned short* bfB = shB.rows;
-    const float* maxnormB_sq = shB.maxnorm_sq;
-    const float* initB = pr.metric == 1 ? shB.init_l2 : shB.init_dot;
-    int nstrips, nsplits, tps;
-    coarse_geometry(pr, &nstrips, &nsplits, &tps);
-    const size_t per = (size_t)nsplits * pr.nA_pad * 2;
+    if (nprobs <= 0 || t.coarse_blocks <= 0) return;
     CoarsePart* part = static_cast<CoarsePart*>(scratch);
-    uint2* lists = reinterpret_cast<uint2*>(static_cast<char*>(scratch) + part_bytes(per));
-    const int dimp = f32_dimp(pr.dim);
-    if (dimp == 64) launch_coarse_t<64>(pr, bfA, bfB, initB, maxnormB_sq, nstrips, nsplits, tps, part, lists, overflow, s);
-    else if (dimp == 128) launch_coarse_t<128>(pr, bfA, bfB, initB, maxnormB_sq, nstrips, nsplits, tps, part, lists, overflow, s);
-    else launch_coarse_t<256>(pr, bfA, bfB, initB, maxnormB_sq, nstrips, nsplits, tps, part, lists, overflow, s);
-    hipLaunchKernelGGL(bf16_rerank_kernel, dim3((pr.nA + kRerankWaves - 1) / kRerankWaves), dim3(kRerankWaves * 64), 0, s,
-                       pr, maxnormB_sq, nsplits, part, lists, j1, j2, k1, k2);
+    uint2* lists = reinterpret_cast<uint2*>(static_cast<char*>(scratch) + part_bytes(t.sublists));
+    const int dimp = f32_dimp(dim);
+    if (dimp == 64) launch_coarse_t<64>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
+    else if (dimp == 128) launch_coarse_t<128>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
+    else launch_coarse_t<256>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
+    if (t.rerank_blocks > 0)
+        hipLaunchKernelGGL(bf16_rerank_kernel, dim3(t.rerank_blocks), dim3(kRerankWaves * 64), 0, s,
+                           d_probs, nprobs, part, lists, j1, j2, k1, k2);
 }
 
 }  // namespace vsm

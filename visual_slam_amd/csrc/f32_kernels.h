@@ -70,10 +70,37 @@ inline Bf16Shadow bf16_shadow_view(const void* base, int n_pad, int dim)
 }
 void launch_bf16_transform(const float* src, int n, int n_pad, int dim, bool dim_major, void* shadow_base,
                            const float* nrm, hipStream_t s);
-size_t bf16_scratch_bytes(const F32Problem& pr);
-// Same outputs as the query side of launch_f32_knn, bit for bit, PROVIDED *overflow (device int)
-// reads 0 afterwards; a set flag means a survivor list was too short and the result is void.
-void launch_bf16_knn(const F32Problem& pr, const Bf16Shadow& shadowA, const Bf16Shadow& shadowB,
-                     int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow, hipStream_t s);
+
+// One directed search of a submission: every row of set A against set B.  A submission is an array
+// of these in device memory; the coarse and re-rank kernels find their problem from the block index.
+struct CoarseProblem {
+    F32Problem pr;
+    const unsigned short* bfA;
+    const unsigned short* bfB;
+    const float* initB;         // accumulator start values of B for pr.metric
+    const float* maxnormB_sq;
+    int32_t nstrips, nsplits, tiles_per_split;
+    int32_t blk0;               // first workgroup of the coarse grid that belongs to this problem
+    int32_t rr_blk0;            // first workgroup of the re-rank grid
+    int32_t reserved;
+    int64_t part_off;           // first survivor sublist (sublists: [split][query][lane half])
+    int64_t out_off;            // first output row in j1 / j2 / k1 / k2
+};
+
+struct CoarseTotals {
+    int coarse_blocks = 0, rerank_blocks = 0;
+    int64_t sublists = 0, out_rows = 0;
+};
+
+// Fills the geometry and offsets of n problems (pr, bf*, initB, maxnormB_sq already set) so that the
+// whole submission has about `target_wgs` coarse workgroups when the databases allow it.
+CoarseTotals plan_coarse(CoarseProblem* probs, int n, int target_wgs);
+size_t coarse_scratch_bytes(const CoarseTotals& t);
+// All problems must share f32_dimp(dim).  Outputs as launch_f32_knn's query side at out_off, bit for
+// bit, PROVIDED *overflow (device int, cleared by the caller) reads 0 afterwards; a set flag means a
+// survivor list was too short and the results are void.
+void launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
+                       int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow,
+                       hipStream_t s);
 
 }  // namespace vsm

@@ -1,0 +1,76 @@
+// Accept tests for float-descriptor pairs, on the device: the tail of the reference's mutual block
+// (Others/SuperPoint_data/models/superglue.py:276-293: argmax both ways, mutual agreement, score
+// threshold, -1 for "no match") plus the optional distance cap and Lowe ratio test of the L2 ranking.
+#include "vsm_internal.h"
+
+#include <math.h>
+
+namespace vsm {
+
+__global__ __launch_bounds__(1024)
+void f32_accept_kernel(const SiftPair* __restrict__ pairs, const F32PairRef* __restrict__ refs, F32Rule rule,
+                       const int32_t* __restrict__ j1, const float* __restrict__ k1, const float* __restrict__ k2,
+                       SiftOutputs out)
+{
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const SiftPair pw = pairs[blockIdx.x];
+    const F32PairRef rf = refs[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid == 0) base_s = 0;
+    if (out.dense0)
+        for (int i = tid; i < pw.nA; i += 1024) out.dense0[pw.out0_off + i] = -1;
+    if (out.dense1)
+        for (int jj = tid; jj < pw.nB; jj += 1024) out.dense1[pw.out1_off + jj] = INT32_MAX;
+    __syncthreads();
+
+    const bool empty = pw.nA == 0 || pw.nB == 0;
+    for (int i0 = 0; i0 < pw.nA && !empty; i0 += 1024) {
+        const int i = i0 + tid;
+        bool ok = false;
+        int j = -1;
+        float best = 0.0f;
+        if (i < pw.nA) {
+            j = j1[rf.fwd_off + i];
+            best = k1[rf.fwd_off + i];
+            ok = j >= 0;
+            if (ok) {
+                if (rule.metric == 0) {
+                    ok = best > rule.min_score;
+                } else {
+                    if (rule.max_dist >= 0.0f && best > rule.max_dist) ok = false;
+                    if (ok && rule.ratio_num > 0 && pw.nB >= 2) {
+                        const double lhs = (double)best * (double)rule.ratio_den * (double)rule.ratio_den;
+                        const double rhs = (double)k2[rf.fwd_off + i] * (double)rule.ratio_num * (double)rule.ratio_num;
+                        ok = lhs < rhs;
+                    }
+                }
+                if (ok && rule.mutual && rf.bwd_off >= 0 && j1[rf.bwd_off + j] != i) ok = false;
+            }
+        }
+        const int slot = block_compact_slot(ok, wsum, &base_s);
+        if (ok) {
+            const size_t o = pw.out0_off + slot;
+            out.slot_i0[o] = i;
+            out.slot_i1[o] = j;
+            if (out.slot_d) out.slot_d[o] = __float_as_int(best);
+            if (out.dense0) out.dense0[pw.out0_off + i] = j;
+            // without the mutual check several rows may name one train row: report the lowest
+            if (out.dense1) atomicMin(&out.dense1[pw.out1_off + j], i);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) out.counts[blockIdx.x] = base_s;
+    if (out.dense1)
+        for (int jj = tid; jj < pw.nB; jj += 1024)
+            if (out.dense1[pw.out1_off + jj] == INT32_MAX) out.dense1[pw.out1_off + jj] = -1;
+}
+
+void launch_f32_accept(const SiftPair* pairs, const F32PairRef* refs, int npairs, F32Rule rule,
+                       const int32_t* j1, const float* k1, const float* k2, SiftOutputs out, hipStream_t s)
+{
+    if (npairs <= 0) return;
+    hipLaunchKernelGGL(f32_accept_kernel, dim3(npairs), dim3(1024), 0, s, pairs, refs, rule, j1, k1, k2, out);
+}
+
+}  // namespace vsm

@@ -405,27 +405,6 @@ void launch_sift_verify(const SiftPair* pairs, const SiftItem* vitems, int nvite
 // ---------------------------------------------------------------------------------
 // block-wide compaction helper (1024 threads)
 // ---------------------------------------------------------------------------------
-// returns this thread's output slot (valid if flag) and advances *base_s by the block total
-__device__ __forceinline__ int block_compact_slot(bool flag, int* wsum, int* base_s)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long bal = __ballot(flag);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[wave] = __popcll(bal);
-    __syncthreads();
-    int woff = 0, tot = 0;
-    for (int w = 0; w < 16; ++w) {
-        const int c = wsum[w];
-        if (w < wave) woff += c;
-        tot += c;
-    }
-    const int base = *base_s;
-    __syncthreads();
-    if (tid == 0) *base_s = base + tot;
-    __syncthreads();
-    return base + woff + before;
-}
-
 // ---- 2. select ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024)
 void sift_select_kernel(const SiftPair* __restrict__ pairs,

@@ -87,10 +87,10 @@ struct vsm_ctx {
     // workspace (grow-only)
     DevBuf d_pairs, d_items, d_rr1, d_rrj, d_rr2, d_colpart, d_cand;
     DevBuf d_slot0, d_slot1, d_slotd, d_counts, d_offsets, d_tight0, d_tight1;
-    DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_flag;
+    DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_flag, d_probs, d_refs;
     // float sets: 0 = bf16 coarse pass + exact re-rank (exact kernel when a survivor list overflows), 1 = exact kernel only
     int f32_mode = 0, last_f32_path = -1;
-    HostBuf h_pairs, h_items, h_small;
+    HostBuf h_pairs, h_items, h_small, h_probs, h_refs;
     // last device-resident result
     int last_npairs = 0;
     long long last_total = 0;
@@ -369,11 +369,14 @@ extern "C" void vsm_destroy(vsm_ctx* c)
     DevBuf* bufs[] = {&c->d_pairs, &c->d_items, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart, &c->d_cand,
                       &c->d_slot0, &c->d_slot1, &c->d_slotd, &c->d_counts, &c->d_offsets,
                       &c->d_tight0, &c->d_tight1, &c->d_dense0, &c->d_dense1,
-                      &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage, &c->d_coarse, &c->d_flag};
+                      &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage, &c->d_coarse, &c->d_flag,
+                      &c->d_probs, &c->d_refs};
     for (DevBuf* b : bufs) b->release();
     c->h_pairs.release();
     c->h_items.release();
     c->h_small.release();
+    c->h_probs.release();
+    c->h_refs.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -565,67 +568,106 @@ struct F32Result {  // device pointers valid until the next submission
     float *k1, *k2, *ck;
 };
 
+CoarseProblem make_problem(const DescSet* A, const DescSet* B, int metric)
+{
+    CoarseProblem p{};
+    p.pr.fragA = static_cast<const float*>(A->frag);
+    p.pr.nrmA = static_cast<const float*>(A->nrm);
+    p.pr.fragB = static_cast<const float*>(B->frag);
+    p.pr.nrmB = static_cast<const float*>(B->nrm);
+    p.pr.nA = A->n; p.pr.nB = B->n; p.pr.nA_pad = A->n_pad; p.pr.nB_pad = B->n_pad;
+    p.pr.dim = A->dim;
+    p.pr.metric = metric;
+    const Bf16Shadow sa = A->shadow_view(), sb = B->shadow_view();
+    p.bfA = sa.rows;
+    p.bfB = sb.rows;
+    p.initB = metric == VSM_METRIC_L2 ? sb.init_l2 : sb.init_dot;
+    p.maxnormB_sq = sb.maxnorm_sq;
+    return p;
+}
+
+// Plans `probs` (non-empty searches only), uploads them and queues the coarse + re-rank kernels.
+// Results land in d_knnj / d_rrj (best and runner-up row) and d_knn1 / d_knn2 (their keys) at each
+// problem's out_off; the overflow flag is cleared first and must be read back by the caller.
+int queue_coarse(vsm_ctx* c, std::vector<CoarseProblem>& probs, int dim, size_t min_rows)
+{
+    const CoarseTotals t = plan_coarse(probs.data(), (int)probs.size(), 1024);
+    const size_t rows = std::max<size_t>(std::max<size_t>((size_t)t.out_rows, min_rows), 1);
+    HIPCHK(c, c->d_knnj.ensure(rows * 4));
+    HIPCHK(c, c->d_rrj.ensure(rows * 4));
+    HIPCHK(c, c->d_knn1.ensure(rows * 4));
+    HIPCHK(c, c->d_knn2.ensure(rows * 4));
+    HIPCHK(c, c->d_coarse.ensure(coarse_scratch_bytes(t)));
+    HIPCHK(c, c->d_flag.ensure(256));
+    HIPCHK(c, c->h_small.ensure(64));
+    HIPCHK(c, hipMemsetAsync(c->d_flag.p, 0, sizeof(int), c->stream));
+    if (probs.empty()) return VSM_OK;
+    const size_t bytes = sizeof(CoarseProblem) * probs.size();
+    HIPCHK(c, c->h_probs.ensure(bytes));
+    HIPCHK(c, c->d_probs.ensure(bytes));
+    memcpy(c->h_probs.p, probs.data(), bytes);
+    HIPCHK(c, hipMemcpyAsync(c->d_probs.p, c->h_probs.p, bytes, hipMemcpyHostToDevice, c->stream));
+    launch_bf16_batch(c->d_probs.as<CoarseProblem>(), (int)probs.size(), dim, t, c->d_knnj.as<int32_t>(),
+                      c->d_rrj.as<int32_t>(), c->d_knn1.as<float>(), c->d_knn2.as<float>(), c->d_coarse.p,
+                      c->d_flag.as<int>(), c->stream);
+    return VSM_OK;
+}
+
+// reads the overflow flag of the last queue_coarse (synchronises the stream)
+int coarse_overflowed(vsm_ctx* c, bool* overflow)
+{
+    int* flag = c->h_small.as<int>() + 8;
+    HIPCHK(c, hipMemcpyAsync(flag, c->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    *overflow = *flag != 0;
+    return VSM_OK;
+}
+
+// One search (optionally also the reverse one for a mutual check); A and B are non-empty.
 int run_f32_knn(vsm_ctx* c, const DescSet* A, const DescSet* B, int metric, bool want_col, F32Result* r)
 {
-    const size_t na = std::max(A->n_pad, 1), nb = std::max(B->n_pad, 1);
-    HIPCHK(c, c->d_knnj.ensure(na * 4));
-    HIPCHK(c, c->d_rrj.ensure(na * 4));
-    HIPCHK(c, c->d_knn1.ensure(na * 4));
-    HIPCHK(c, c->d_knn2.ensure(na * 4));
-    HIPCHK(c, c->d_dense1.ensure(nb * 4));
-    HIPCHK(c, c->d_rr1.ensure(nb * 4));
-    r->j1 = c->d_knnj.as<int32_t>();
-    r->j2 = c->d_rrj.as<int32_t>();
-    r->k1 = c->d_knn1.as<float>();
-    r->k2 = c->d_knn2.as<float>();
-    r->cidx = c->d_dense1.as<int32_t>();
-    r->ck = c->d_rr1.as<float>();
-    F32Problem pr;
-    pr.fragA = static_cast<const float*>(A->frag);
-    pr.nrmA = static_cast<const float*>(A->nrm);
-    pr.fragB = static_cast<const float*>(B->frag);
-    pr.nrmB = static_cast<const float*>(B->nrm);
-    pr.nA = A->n; pr.nB = B->n; pr.nA_pad = A->n_pad; pr.nB_pad = B->n_pad;
-    pr.dim = A->dim;
-    pr.metric = metric;
+    const size_t rows = (size_t)A->n_pad + B->n_pad;
     c->ev_valid = false;
+    int rc;
     if (c->f32_mode == 0) {
         // bf16 coarse pass + exact re-rank; the train side of a mutual check is the same search
-        // with the roles swapped (its runner-up outputs land in spare buffers)
-        F32Problem sw = pr;
-        sw.fragA = pr.fragB; sw.nrmA = pr.nrmB; sw.fragB = pr.fragA; sw.nrmB = pr.nrmA;
-        sw.nA = pr.nB; sw.nB = pr.nA; sw.nA_pad = pr.nB_pad; sw.nB_pad = pr.nA_pad;
-        size_t need = bf16_scratch_bytes(pr);
-        if (want_col) need = std::max(need, bf16_scratch_bytes(sw));
-        HIPCHK(c, c->d_coarse.ensure(need));
-        HIPCHK(c, c->d_flag.ensure(256));
-        HIPCHK(c, c->h_small.ensure(64));
-        if (want_col) {
-            HIPCHK(c, c->d_slot1.ensure(nb * 4));
-            HIPCHK(c, c->d_slotd.ensure(nb * 4));
-        }
+        // with the roles swapped
+        std::vector<CoarseProblem> probs;
+        probs.push_back(make_problem(A, B, metric));
+        if (want_col) probs.push_back(make_problem(B, A, metric));
         if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_flag.p, 0, sizeof(int), c->stream));
-        launch_bf16_knn(pr, A->shadow_view(), B->shadow_view(), r->j1, r->j2, r->k1, r->k2, c->d_coarse.p,
-                        c->d_flag.as<int>(), c->stream);
-        if (want_col)
-            launch_bf16_knn(sw, B->shadow_view(), A->shadow_view(), r->cidx, c->d_slot1.as<int32_t>(), r->ck,
-                            c->d_slotd.as<float>(), c->d_coarse.p, c->d_flag.as<int>(), c->stream);
+        if ((rc = queue_coarse(c, probs, A->dim, rows)) != VSM_OK) return rc;
         if (c->timing) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        int* flag = c->h_small.as<int>();
-        HIPCHK(c, hipMemcpyAsync(flag, c->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipGetLastError());
-        if (*flag == 0) {
+        bool overflow = false;
+        if ((rc = coarse_overflowed(c, &overflow)) != VSM_OK) return rc;
+        if (!overflow) {
+            r->j1 = c->d_knnj.as<int32_t>();
+            r->j2 = c->d_rrj.as<int32_t>();
+            r->k1 = c->d_knn1.as<float>();
+            r->k2 = c->d_knn2.as<float>();
+            r->cidx = r->j1 + A->n_pad;
+            r->ck = r->k1 + A->n_pad;
             c->ev_valid = c->timing != 0;
             c->last_f32_path = 0;
             return VSM_OK;
         }
         // a survivor list overflowed (heavily tied or adversarially ordered scores): exact kernel
     }
+    HIPCHK(c, c->d_knnj.ensure(rows * 4));
+    HIPCHK(c, c->d_rrj.ensure(rows * 4));
+    HIPCHK(c, c->d_knn1.ensure(rows * 4));
+    HIPCHK(c, c->d_knn2.ensure(rows * 4));
+    r->j1 = c->d_knnj.as<int32_t>();
+    r->j2 = c->d_rrj.as<int32_t>();
+    r->k1 = c->d_knn1.as<float>();
+    r->k2 = c->d_knn2.as<float>();
+    r->cidx = r->j1 + A->n_pad;
+    r->ck = r->k1 + A->n_pad;
+    const CoarseProblem p = make_problem(A, B, metric);
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    HIPCHK(c, c->d_colpart.ensure(f32_scratch_bytes(pr, want_col)));
-    launch_f32_knn(pr, r->j1, r->j2, r->k1, r->k2, want_col ? r->cidx : nullptr, want_col ? r->ck : nullptr,
+    HIPCHK(c, c->d_colpart.ensure(f32_scratch_bytes(p.pr, want_col)));
+    launch_f32_knn(p.pr, r->j1, r->j2, r->k1, r->k2, want_col ? r->cidx : nullptr, want_col ? r->ck : nullptr,
                    c->d_colpart.p, c->stream);
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
@@ -678,6 +720,182 @@ int match_pair_f32(vsm_ctx* c, const DescSet* A, const DescSet* B, const vsm_par
     return nm;
 }
 
+// ---- submissions of float pairs: coarse + re-rank for every search, accept tests on the device ----
+struct F32Plan {
+    std::vector<CoarseProblem> probs;
+    std::vector<SiftPair> pairs;     // only the counts and output offsets are used
+    std::vector<F32PairRef> refs;    // problem indices while planning, row offsets once planned
+    size_t out0 = 0, out1 = 0;
+    int dim = 0;
+};
+
+int plan_f32(vsm_ctx* c, const int32_t* pairs, int npairs, int metric, bool mutual, F32Plan& pl)
+{
+    pl.pairs.resize(npairs);
+    pl.refs.resize(npairs);
+    for (int p = 0; p < npairs; ++p) {
+        const DescSet* A = get_set(c, pairs[2 * p]);
+        const DescSet* B = get_set(c, pairs[2 * p + 1]);
+        if (!A || !B) return fail(c, VSM_EINVAL, "pair %d names an unknown set", p);
+        if (A->kind != SET_F32 || B->kind != SET_F32) return fail(c, VSM_EINVAL, "pair %d mixes set kinds", p);
+        if (A->dim != B->dim) return fail(c, VSM_EINVAL, "pair %d: sets differ in dimension", p);
+        if (pl.dim == 0) pl.dim = A->dim;
+        if (f32_dimp(A->dim) != f32_dimp(pl.dim))
+            return fail(c, VSM_EINVAL, "pair %d: one submission takes one padded dimension (64, 128 or 256)", p);
+        SiftPair sp{};
+        sp.nA = A->n; sp.nB = B->n; sp.nA_pad = A->n_pad; sp.nB_pad = B->n_pad;
+        sp.out0_off = (int64_t)pl.out0;
+        sp.out1_off = (int64_t)pl.out1;
+        pl.out0 += (size_t)A->n;
+        pl.out1 += (size_t)B->n;
+        pl.pairs[p] = sp;
+        F32PairRef rf{-1, -1};
+        if (A->n > 0 && B->n > 0) {
+            rf.fwd_off = (int64_t)pl.probs.size();
+            pl.probs.push_back(make_problem(A, B, metric));
+            if (mutual) {
+                rf.bwd_off = (int64_t)pl.probs.size();
+                pl.probs.push_back(make_problem(B, A, metric));
+            }
+        }
+        pl.refs[p] = rf;
+    }
+    if (pl.dim == 0) pl.dim = 256;
+    return VSM_OK;
+}
+
+F32Rule make_f32_rule(const vsm_params* p, int metric)
+{
+    F32Rule r;
+    r.metric = metric;
+    r.mutual = p->mutual ? 1 : 0;
+    r.ratio_num = p->ratio_num;
+    r.ratio_den = p->ratio_den;
+    r.min_score = p->min_score;
+    r.max_dist = p->max_dist_sq_f;
+    return r;
+}
+
+// Queues the whole float pipeline for one planned submission; the caller reads the overflow flag.
+int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o)
+{
+    const int npairs = (int)pl.pairs.size();
+    c->ev_valid = false;
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    int rc = queue_coarse(c, pl.probs, pl.dim, 0);
+    if (rc) return rc;
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        c->ev_valid = true;
+    }
+    for (F32PairRef& rf : pl.refs) {
+        if (rf.fwd_off >= 0) rf.fwd_off = pl.probs[rf.fwd_off].out_off;
+        if (rf.bwd_off >= 0) rf.bwd_off = pl.probs[rf.bwd_off].out_off;
+    }
+    HIPCHK(c, c->h_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
+    HIPCHK(c, c->d_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
+    HIPCHK(c, c->h_refs.ensure(sizeof(F32PairRef) * std::max(npairs, 1)));
+    HIPCHK(c, c->d_refs.ensure(sizeof(F32PairRef) * std::max(npairs, 1)));
+    const size_t n0 = std::max<size_t>(pl.out0, 1), n1 = std::max<size_t>(pl.out1, 1);
+    HIPCHK(c, c->d_slot0.ensure(n0 * 4));
+    HIPCHK(c, c->d_slot1.ensure(n0 * 4));
+    if (o.want_dist) HIPCHK(c, c->d_slotd.ensure(n0 * 4));
+    HIPCHK(c, c->d_counts.ensure(sizeof(int32_t) * std::max(npairs, 1)));
+    HIPCHK(c, c->d_offsets.ensure(sizeof(int64_t) * (npairs + 1)));
+    if (o.want_pack) {
+        HIPCHK(c, c->d_tight0.ensure(n0 * 4));
+        HIPCHK(c, c->d_tight1.ensure(n0 * 4));
+    }
+    if (o.want_dense) {
+        HIPCHK(c, c->d_dense0.ensure(n0 * 4));
+        HIPCHK(c, c->d_dense1.ensure(n1 * 4));
+    }
+    if (npairs == 0) {
+        HIPCHK(c, hipMemsetAsync(c->d_offsets.p, 0, sizeof(int64_t), c->stream));
+        return VSM_OK;
+    }
+    memcpy(c->h_pairs.p, pl.pairs.data(), sizeof(SiftPair) * npairs);
+    memcpy(c->h_refs.p, pl.refs.data(), sizeof(F32PairRef) * npairs);
+    HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->h_pairs.p, sizeof(SiftPair) * npairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_refs.p, c->h_refs.p, sizeof(F32PairRef) * npairs, hipMemcpyHostToDevice, c->stream));
+    SiftOutputs out{};
+    out.slot_i0 = c->d_slot0.as<int32_t>();
+    out.slot_i1 = c->d_slot1.as<int32_t>();
+    out.slot_d = o.want_dist ? c->d_slotd.as<int32_t>() : nullptr;
+    out.counts = c->d_counts.as<int32_t>();
+    out.dense0 = o.want_dense ? c->d_dense0.as<int32_t>() : nullptr;
+    out.dense1 = o.want_dense ? c->d_dense1.as<int32_t>() : nullptr;
+    launch_f32_accept(c->d_pairs.as<SiftPair>(), c->d_refs.as<F32PairRef>(), npairs, rule, c->d_knnj.as<int32_t>(),
+                      c->d_knn1.as<float>(), c->d_knn2.as<float>(), out, c->stream);
+    if (o.want_pack)
+        launch_pack(c->d_pairs.as<SiftPair>(), npairs, out.counts, c->d_offsets.as<int64_t>(), out.slot_i0, out.slot_i1,
+                    c->d_tight0.as<int32_t>(), c->d_tight1.as<int32_t>(), c->stream);
+    HIPCHK(c, hipGetLastError());
+    return VSM_OK;
+}
+
+// Fast path for a submission of float pairs.  *done = false when the context is in f32-only mode or a
+// survivor list overflowed: the caller then takes the per-pair path on the f32 kernel.
+int f32_pairs_fast(vsm_ctx* c, const int32_t* pairs, int npairs, const vsm_params* p, int metric,
+                   const RunOpts& o, bool* done)
+{
+    *done = false;
+    if (c->f32_mode != 0) return VSM_OK;
+    F32Plan pl;
+    int rc = plan_f32(c, pairs, npairs, metric, p->mutual != 0, pl);
+    if (rc) return rc;
+    if ((rc = run_f32_batch(c, pl, make_f32_rule(p, metric), o)) != VSM_OK) return rc;
+    bool overflow = false;
+    if ((rc = coarse_overflowed(c, &overflow)) != VSM_OK) return rc;
+    if (overflow) {
+        c->ev_valid = false;
+        return VSM_OK;
+    }
+    c->last_f32_path = 0;
+    *done = true;
+    return VSM_OK;
+}
+
+// Per-pair path on the f32 kernel; leaves offsets and tight lists on the device like a submission.
+long long f32_pairs_slow(vsm_ctx* c, const int32_t* pairs, int npairs, const vsm_params* p, int metric)
+{
+    std::vector<int64_t> off(npairs + 1, 0);
+    std::vector<int32_t> i0, i1, m0;
+    const int saved = c->f32_mode;
+    c->f32_mode = 1;
+    for (int k = 0; k < npairs; ++k) {
+        const DescSet* A = get_set(c, pairs[2 * k]);
+        const DescSet* B = get_set(c, pairs[2 * k + 1]);
+        if (!A || !B || A->kind != SET_F32 || B->kind != SET_F32 || A->dim != B->dim) {
+            c->f32_mode = saved;
+            return fail(c, VSM_EINVAL, "pair %d is not a pair of float sets of one dimension", k);
+        }
+        m0.assign(std::max(A->n, 1), -1);
+        const int nm = match_pair_f32(c, A, B, p, metric, m0.data(), nullptr, nullptr);
+        if (nm < 0) {
+            c->f32_mode = saved;
+            return nm;
+        }
+        for (int i = 0; i < A->n; ++i)
+            if (m0[i] >= 0) {
+                i0.push_back(i);
+                i1.push_back(m0[i]);
+            }
+        off[k + 1] = (int64_t)i0.size();
+    }
+    c->f32_mode = saved;
+    const size_t tot = i0.size();
+    HIPCHK(c, c->d_offsets.ensure(sizeof(int64_t) * (npairs + 1)));
+    HIPCHK(c, c->d_tight0.ensure(std::max<size_t>(tot, 1) * 4));
+    HIPCHK(c, c->d_tight1.ensure(std::max<size_t>(tot, 1) * 4));
+    HIPCHK(c, hipMemcpy(c->d_offsets.p, off.data(), sizeof(int64_t) * (npairs + 1), hipMemcpyHostToDevice));
+    if (tot) {
+        HIPCHK(c, hipMemcpy(c->d_tight0.p, i0.data(), tot * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_tight1.p, i1.data(), tot * 4, hipMemcpyHostToDevice));
+    }
+    return (long long)tot;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------
@@ -686,16 +904,29 @@ int match_pair_f32(vsm_ctx* c, const DescSet* A, const DescSet* B, const vsm_par
 extern "C" long long vsm_match_pairs_device(vsm_ctx* c, const int32_t* pairs, int npairs,
                                             const vsm_params* p, int metric)
 {
-    (void)metric;
     if (!c) return VSM_EINVAL;
     if (npairs < 0 || (npairs > 0 && !pairs)) return fail(c, VSM_EINVAL, "bad pair list");
     int rc = check_params(c, p);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
-    Plan pl;
-    if ((rc = plan_u8(c, pairs, npairs, pl)) != VSM_OK) return rc;
+    const DescSet* first = npairs > 0 ? get_set(c, pairs[0]) : nullptr;
+    const bool float_sets = first && first->kind == SET_F32;
     RunOpts o;
-    if ((rc = run_u8(c, pl, make_rule(p), o)) != VSM_OK) return rc;
+    if (float_sets) {
+        bool done = false;
+        if ((rc = f32_pairs_fast(c, pairs, npairs, p, metric, o, &done)) != VSM_OK) return rc;
+        if (!done) {
+            const long long got = f32_pairs_slow(c, pairs, npairs, p, metric);
+            if (got < 0) return got;
+            c->last_npairs = npairs;
+            c->last_total = got;
+            return got;
+        }
+    } else {
+        Plan pl;
+        if ((rc = plan_u8(c, pairs, npairs, pl)) != VSM_OK) return rc;
+        if ((rc = run_u8(c, pl, make_rule(p), o)) != VSM_OK) return rc;
+    }
     HIPCHK(c, c->h_small.ensure(64));
     long long* tot = c->h_small.as<long long>();
     *tot = 0;
@@ -749,7 +980,9 @@ extern "C" long long vsm_match_pairs(vsm_ctx* c, const int32_t* pairs, int npair
             const DescSet* B = get_set(c, pairs[2 * (done + take) + 1]);
             if (!A || !B) return fail(c, VSM_EINVAL, "pair %d names an unknown set", done + take);
             const size_t chunks = ((size_t)B->n_pad + kChunkCols - 1) / kChunkCols;
-            const size_t need = (chunks * A->n_pad + A->n) * kScratchPerRow;
+            const size_t need = A->kind == SET_F32
+                                    ? ((size_t)A->n_pad + B->n_pad) * 2 * (kCoarseCap * 8 + 16 + 64)
+                                    : (chunks * A->n_pad + A->n) * kScratchPerRow;
             if (take > 0 && (scratch + need > kScratchBudget / 2 || take >= 8192)) break;
             scratch += need;
             ++take;
@@ -780,6 +1013,26 @@ extern "C" int vsm_match_pair(vsm_ctx* c, int set0, int set1, const vsm_params* 
     if (kind == SET_F32) {
         const DescSet* A = get_set(c, set0);
         const DescSet* B = get_set(c, set1);
+        const int32_t one[2] = {set0, set1};
+        RunOpts fo;
+        fo.want_dist = dist != nullptr;
+        fo.want_pack = false;
+        bool done = false;
+        if ((rc = f32_pairs_fast(c, one, 1, p, metric, fo, &done)) != VSM_OK) return rc;
+        if (done) {
+            int32_t* cnt = c->h_small.as<int32_t>();
+            HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const int nm = *cnt;
+            if (nm > cap) return fail(c, VSM_ECAP, "%d matches do not fit a buffer of %d", nm, cap);
+            if (nm > 0) {
+                if (idx0) HIPCHK(c, hipMemcpyAsync(idx0, c->d_slot0.p, sizeof(int32_t) * nm, hipMemcpyDeviceToHost, c->stream));
+                if (idx1) HIPCHK(c, hipMemcpyAsync(idx1, c->d_slot1.p, sizeof(int32_t) * nm, hipMemcpyDeviceToHost, c->stream));
+                if (dist) HIPCHK(c, hipMemcpyAsync(dist, c->d_slotd.p, sizeof(float) * nm, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+            }
+            return nm;
+        }
         std::vector<int32_t> m0(std::max(A->n, 1));
         std::vector<float> b0(std::max(A->n, 1));
         const int nm = match_pair_f32(c, A, B, p, metric, m0.data(), nullptr, b0.data());
@@ -829,7 +1082,21 @@ extern "C" int vsm_match_pair_dense(vsm_ctx* c, int set0, int set1, const vsm_pa
     HIPCHK(c, hipSetDevice(c->device));
     const DescSet* A = get_set(c, set0);
     const DescSet* B = get_set(c, set1);
-    if (kind == SET_F32) return match_pair_f32(c, A, B, p, metric, matches0, matches1, nullptr);
+    if (kind == SET_F32) {
+        const int32_t one[2] = {set0, set1};
+        RunOpts fo;
+        fo.want_dense = true;
+        fo.want_pack = false;
+        bool done = false;
+        if ((rc = f32_pairs_fast(c, one, 1, p, metric, fo, &done)) != VSM_OK) return rc;
+        if (!done) return match_pair_f32(c, A, B, p, metric, matches0, matches1, nullptr);
+        int32_t* cnt = c->h_small.as<int32_t>();
+        HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (A->n) HIPCHK(c, hipMemcpyAsync(matches0, c->d_dense0.p, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
+        if (B->n) HIPCHK(c, hipMemcpyAsync(matches1, c->d_dense1.p, sizeof(int32_t) * B->n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return *cnt;
+    }
     const int32_t pr[2] = {set0, set1};
     Plan pl;
     if ((rc = plan_u8(c, pr, 1, pl)) != VSM_OK) return rc;

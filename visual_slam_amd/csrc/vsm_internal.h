@@ -22,7 +22,7 @@ namespace vsm {
 constexpr int kDescDim = 128;
 constexpr int kRowPad = 512;
 constexpr int kTileBytes = 4096;      // 32 rows * 128 bytes
-constexpr int kStripRows = 512;       // query rows per workgroup of the query pass (8 waves * 64)
+constexpr int kStripRows = 512;       // query rows per workgroup of the query pass (4 waves * 128)
 constexpr int kVerifyBlock = 256;     // candidates per workgroup of the verify pass (8 waves * 32)
 constexpr int kStepRows = 256;        // streamed rows per main-loop step
 constexpr int kChunkCols = 8192;      // streamed rows per work item of the query-side pass
@@ -77,6 +77,44 @@ struct SiftOutputs {
     int32_t* knn_d1;
     int32_t* knn_d2;
 };
+
+// Block-wide stream compaction step for 1024-thread blocks: returns this thread's output slot
+// (meaningful if flag) and advances *base_s by the number of flagged threads.  wsum: 16 ints of LDS.
+__device__ __forceinline__ int block_compact_slot(bool flag, int* wsum, int* base_s)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+        const int c = wsum[w];
+        if (w < wave) woff += c;
+        tot += c;
+    }
+    const int base = *base_s;
+    __syncthreads();
+    if (tid == 0) *base_s = base + tot;
+    __syncthreads();
+    return base + woff + before;
+}
+
+// ---- float path: accept tests of a submission of pairs ---------------------------------
+struct F32PairRef {
+    int64_t fwd_off;   // rows of the image-0 -> image-1 search in the j1 / k1 / k2 arrays
+    int64_t bwd_off;   // rows of the image-1 -> image-0 search (mutual check); < 0: none
+};
+struct F32Rule {
+    int32_t metric, mutual;
+    int32_t ratio_num, ratio_den;   // num <= 0 disables
+    float min_score;                // dot ranking: accept iff best > min_score
+    float max_dist;                 // L2 ranking: accept iff best <= max_dist; < 0 disables
+};
+// One block per pair; only nA, nB, out0_off and out1_off of SiftPair are read.  slot_d receives the
+// bits of the best key of every accepted row.
+void launch_f32_accept(const SiftPair* pairs, const F32PairRef* refs, int npairs, F32Rule rule,
+                       const int32_t* j1, const float* k1, const float* k2, SiftOutputs out, hipStream_t s);
 
 void launch_sift_transform(const uint8_t* des, int n, int n_pad, int8_t* frag, int32_t* nrm8c,
                            hipStream_t s);
