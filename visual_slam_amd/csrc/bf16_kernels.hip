@@ -47,7 +47,8 @@ __device__ __forceinline__ unsigned f32_to_bf16_rne(float x)
 }
 
 __global__ void bf16_transform_kernel(const float* __restrict__ src, int n, int n_pad, int dim, int dimp,
-                                      int dim_major, unsigned short* __restrict__ shadow)
+                                      int dim_major, unsigned short* __restrict__ shadow,
+                                      float* __restrict__ rows_f32)
 {
     // one thread per (row, k-step, half): 8 consecutive k
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,13 +59,18 @@ __global__ void bf16_transform_kernel(const float* __restrict__ src, int n, int 
     const int s = (int)((gid >> 1) % steps);
     const int row = (int)((gid >> 1) / steps);
     unsigned v[8];
+    float f[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = 16 * s + 8 * h + j;
         float x = 0.0f;
         if (row < n && k < dim) x = dim_major ? src[(size_t)k * n + row] : src[(size_t)row * dim + k];
+        f[j] = x;
         v[j] = f32_to_bf16_rne(x);
     }
+    float4* plain = reinterpret_cast<float4*>(rows_f32 + (size_t)row * dimp + 16 * s + 8 * h);
+    plain[0] = make_float4(f[0], f[1], f[2], f[3]);
+    plain[1] = make_float4(f[4], f[5], f[6], f[7]);
     const int tile = row >> 5, r = row & 31;
     uint4 out;
     out.x = v[0] | (v[1] << 16);
@@ -99,7 +105,7 @@ void launch_bf16_transform(const float* src, int n, int n_pad, int dim, bool dim
     const int dimp = f32_dimp(dim);
     const long long total = (long long)n_pad * (dimp / 16) * 2;
     hipLaunchKernelGGL(bf16_transform_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       src, n, n_pad, dim, dimp, dim_major ? 1 : 0, shadow);
+                       src, n, n_pad, dim, dimp, dim_major ? 1 : 0, shadow, const_cast<float*>(v.rows_f32));
     (void)hipMemsetAsync(maxnorm_sq, 0, sizeof(float), s);
     const int slots = n_pad + 64;
     hipLaunchKernelGGL(max_norm_kernel, dim3(std::min(64, (slots + 255) / 256)), dim3(256), 0, s, nrm, n, slots,
@@ -261,7 +267,7 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const float x = acc[rb][reg];
-                        if (x >= thr[rb] && x > -INFINITY) {
+                        if (x >= thr[rb]) {   // padding rows (-inf) get in only while thr is -inf; the re-rank drops them
                             const int rin = (reg & 3) + 8 * (reg >> 2) + 4 * half;
                             if (cnt[rb] < kCoarseCap)
                                 mylist[cnt[rb]] = make_uint2((unsigned)(tile * 32 + rin), __float_as_uint(x));
@@ -302,9 +308,8 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
 // ---------------------------------------------------------------------------------
 // One wave per query.  Lane l first folds the coarse top-2 of sublist l into the query's final coarse
 // runner-up T2, then the wave walks the concatenated survivor lists 64 entries at a time, keeps the
-// entries with coarse score >= T2 - margin, and scores those exactly: one lane per surviving row runs
-// the k-ascending fmaf chain on the f32 rows (fragment-major layout: in group g, float4 number
-// g*64 + h*32 + r of a tile holds k = 8g + h, 8g + 2 + h, 8g + 4 + h, 8g + 6 + h of row r).
+// entries with coarse score >= T2 - margin, and scores those exactly with the k-ascending fmaf chain on
+// the plain row-major f32 copies of the two rows.
 constexpr int kRerankWaves = 4;
 
 struct Best2 {
@@ -327,58 +332,51 @@ __device__ __forceinline__ void best2_insert(Best2& b, float sc, int row)
     }
 }
 
-__device__ __forceinline__ float exact_dot(const float* fragA, const float* fragB, int dimp, int ia, int ib)
-{
-    const float4* pa = reinterpret_cast<const float4*>(fragA + (size_t)(ia >> 5) * 32 * dimp) + (ia & 31);
-    const float4* pb = reinterpret_cast<const float4*>(fragB + (size_t)(ib >> 5) * 32 * dimp) + (ib & 31);
-    float d = 0.0f;
-    for (int g = 0; g < dimp / 8; ++g) {
-        const float4 a0 = pa[g * 64], a1 = pa[g * 64 + 32];
-        const float4 b0 = pb[g * 64], b1 = pb[g * 64 + 32];
-        d = fmaf(b0.x, a0.x, d); d = fmaf(b1.x, a1.x, d);
-        d = fmaf(b0.y, a0.y, d); d = fmaf(b1.y, a1.y, d);
-        d = fmaf(b0.z, a0.z, d); d = fmaf(b1.z, a1.z, d);
-        d = fmaf(b0.w, a0.w, d); d = fmaf(b1.w, a1.w, d);
-    }
-    return d;
-}
-
+// Exact scores of up to eight surviving rows at a time: eight lanes per row, lane `sub` of a group
+// holds columns [sub * DIMP/8, (sub + 1) * DIMP/8) of the row (one round trip to memory for the whole
+// row), and the k-ascending fmaf chain runs through the group's lanes in order, handed on by a
+// shuffle.  The query row sits in LDS.
+template <int DIMP>
 __global__ __launch_bounds__(kRerankWaves * 64)
 void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
                         const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
                         int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
                         float* __restrict__ k1_all, float* __restrict__ k2_all)
 {
+    constexpr int Q = DIMP / 32;   // float4 pieces of a row per lane
     __shared__ int s_rows[kRerankWaves][64];
+    __shared__ __attribute__((aligned(16))) float s_a[kRerankWaves][DIMP];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int pi = find_problem(nprobs, (int)blockIdx.x, [&](int i) { return probs[i].rr_blk0; });
-    const CoarseProblem& P = probs[pi];
+    // grid: x = block of kRerankWaves queries, y = problem (no search: a re-rank wave is short)
+    const CoarseProblem& P = probs[blockIdx.y];
     const F32Problem pr = P.pr;
     const int nsplits = P.nsplits;
-    const float* maxnormB_sq = P.maxnormB_sq;
     const CoarsePart* __restrict__ part = part_all + P.part_off;
     const uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
-    int32_t* __restrict__ j1 = j1_all + P.out_off;
-    int32_t* __restrict__ j2 = j2_all + P.out_off;
-    float* __restrict__ k1 = k1_all + P.out_off;
-    float* __restrict__ k2 = k2_all + P.out_off;
-    const int i = ((int)blockIdx.x - P.rr_blk0) * kRerankWaves + wave;
-    if (i >= pr.nA) return;   // the whole wave leaves; no workgroup barrier below
+    const int i = (int)blockIdx.x * kRerankWaves + wave;
+    const bool live = i < pr.nA;
+    if (live && lane * 4 < DIMP)
+        *reinterpret_cast<float4*>(&s_a[wave][lane * 4]) =
+            *reinterpret_cast<const float4*>(P.rowsA + (size_t)i * DIMP + lane * 4);
+    __syncthreads();   // the only workgroup barrier: everything below is per wave
+    if (!live) return;
+
     volatile int* rows = s_rows[wave];
     const bool l2 = pr.metric == 1;
-    const int dimp = f32_dimp(pr.dim);
     const float na = pr.nrmA[i];
-    const float margin = coarse_margin(l2, na, *maxnormB_sq);
+    const float margin = coarse_margin(l2, na, *P.maxnormB_sq);
     const int nsub = nsplits * 2;
     auto sub_index = [&](int sid) { return ((size_t)(sid >> 1) * pr.nA_pad + i) * 2 + (sid & 1); };
 
     // final coarse runner-up over all splits and both lane halves
     float T1 = -INFINITY, T2 = -INFINITY;
+    int cnt_first = 0;   // list length of sublist `lane` (first chunk of 64 sublists)
     for (int sid = lane; sid < nsub; sid += 64) {
         const CoarsePart cp = part[sub_index(sid)];
         T2 = fmaxf(fmaxf(T2, cp.t2), fminf(T1, cp.t1));
         T1 = fmaxf(T1, cp.t1);
+        if (sid == lane) cnt_first = cp.count;
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -391,19 +389,43 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
     Best2 best;
     best.s1 = -INFINITY; best.s2 = -INFINITY; best.r1 = -1; best.r2 = -1;
     int npending = 0;   // wave-uniform: rows waiting in `rows`
+    const int sub = lane & 7, grp = lane >> 3;
+    const float4* a4 = reinterpret_cast<const float4*>(&s_a[wave][0]) + sub * Q;
     auto flush = [&]() {
-        if (lane < npending) {
-            const int row = rows[lane];
-            const float d = exact_dot(pr.fragA, pr.fragB, dimp, i, row);
-            const float sc = l2 ? fmaf(2.0f, d, -pr.nrmB[row]) : d;
-            if (sc > -INFINITY) best2_insert(best, sc, row);
+        for (int base = 0; base < npending; base += 8) {
+            const bool act = base + grp < npending;
+            const int row = act ? rows[base + grp] : 0;
+            const float4* pb = reinterpret_cast<const float4*>(P.rowsB + (size_t)row * DIMP) + sub * Q;
+            float4 b[Q];
+#pragma unroll
+            for (int u = 0; u < Q; ++u) b[u] = pb[u];
+            const float nbr = pr.nrmB[row];
+            float d = 0.0f;
+#pragma unroll
+            for (int stage = 0; stage < 8; ++stage) {
+                if (sub == stage) {
+#pragma unroll
+                    for (int u = 0; u < Q; ++u) {
+                        const float4 a = a4[u];
+                        d = fmaf(b[u].x, a.x, d);
+                        d = fmaf(b[u].y, a.y, d);
+                        d = fmaf(b[u].z, a.z, d);
+                        d = fmaf(b[u].w, a.w, d);
+                    }
+                }
+                const float handed = __shfl(d, (lane & ~7) + stage);
+                if (sub == stage + 1) d = handed;
+                if (stage == 7) d = handed;   // the finished chain, in every lane of the group
+            }
+            const float sc = l2 ? fmaf(2.0f, d, -nbr) : d;
+            if (act && sub == 0 && sc > -INFINITY) best2_insert(best, sc, row);
         }
         npending = 0;
     };
 
     for (int chunk = 0; chunk < nsub; chunk += 64) {
         const int sid = chunk + lane;
-        const int cnt = sid < nsub ? part[sub_index(sid)].count : 0;
+        const int cnt = chunk == 0 ? cnt_first : (sid < nsub ? part[sub_index(sid)].count : 0);
         int incl = cnt;   // inclusive prefix sum of the chunk's list lengths
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -426,8 +448,8 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
             int row = 0;
             if (e < total) {
                 const uint2 en = lists[sub_index(chunk + lo) * kCoarseCap + within];
-                keep = __uint_as_float(en.y) >= thr;
                 row = (int)en.x;
+                keep = __uint_as_float(en.y) >= thr && row < pr.nB;
             }
             const unsigned long long mask = __ballot(keep);
             const int n = __popcll(mask);
@@ -449,10 +471,11 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
         if (o.r2 >= 0) best2_insert(best, o.s2, o.r2);
     }
     if (lane == 0) {
-        j1[i] = best.r1;
-        j2[i] = best.r2;
-        k1[i] = best.r1 < 0 ? (l2 ? INFINITY : -INFINITY) : (l2 ? fmaxf(-best.s1 + na, 0.0f) : best.s1);
-        k2[i] = best.r2 < 0 ? (l2 ? INFINITY : -INFINITY) : (l2 ? fmaxf(-best.s2 + na, 0.0f) : best.s2);
+        const int64_t o = P.out_off + i;
+        j1_all[o] = best.r1;
+        j2_all[o] = best.r2;
+        k1_all[o] = best.r1 < 0 ? (l2 ? INFINITY : -INFINITY) : (l2 ? fmaxf(-best.s1 + na, 0.0f) : best.s1);
+        k2_all[o] = best.r2 < 0 ? (l2 ? INFINITY : -INFINITY) : (l2 ? fmaxf(-best.s2 + na, 0.0f) : best.s2);
     }
 }
 
@@ -475,12 +498,12 @@ CoarseTotals plan_coarse(CoarseProblem* probs, int n, int target_wgs)
         p.tiles_per_split = tps;
         p.nsplits = std::max(1, (ntiles + tps - 1) / tps);
         p.blk0 = t.coarse_blocks;
-        p.rr_blk0 = t.rerank_blocks;
+        p.rr_blk0 = 0;
         p.reserved = 0;
         p.part_off = t.sublists;
         p.out_off = t.out_rows;
         t.coarse_blocks += p.nstrips * p.nsplits;
-        t.rerank_blocks += (p.pr.nA + kRerankWaves - 1) / kRerankWaves;
+        t.rerank_blocks = std::max(t.rerank_blocks, (p.pr.nA + kRerankWaves - 1) / kRerankWaves);
         t.sublists += (int64_t)p.nsplits * p.pr.nA_pad * 2;
         t.out_rows += p.pr.nA_pad;
     }
@@ -520,9 +543,12 @@ void launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const 
     if (dimp == 64) launch_coarse_t<64>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
     else if (dimp == 128) launch_coarse_t<128>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
     else launch_coarse_t<256>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
-    if (t.rerank_blocks > 0)
-        hipLaunchKernelGGL(bf16_rerank_kernel, dim3(t.rerank_blocks), dim3(kRerankWaves * 64), 0, s,
-                           d_probs, nprobs, part, lists, j1, j2, k1, k2);
+    if (t.rerank_blocks > 0) {
+        const dim3 grid(t.rerank_blocks, nprobs), block(kRerankWaves * 64);
+        if (dimp == 64) hipLaunchKernelGGL(bf16_rerank_kernel<64>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+        else if (dimp == 128) hipLaunchKernelGGL(bf16_rerank_kernel<128>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+        else hipLaunchKernelGGL(bf16_rerank_kernel<256>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+    }
 }
 
 }  // namespace vsm

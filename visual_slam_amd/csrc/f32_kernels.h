@@ -45,18 +45,22 @@ void launch_f32_knn(const F32Problem& pr, int32_t* j1, int32_t* j2, float* k1, f
 constexpr int kCoarseCap = 128;  // survivors one (split, query, lane half) list can hold
 
 // One allocation per set: [bf16 rows][256 B holding maxnorm_sq][init_l2: n_pad + 64 floats]
-// [init_dot: n_pad + 64 floats].  The init arrays are the accumulator start values of the coarse
-// kernel: -|b|^2 / 2 resp. 0 for real rows, -inf for padding rows.
+// [init_dot: n_pad + 64 floats][plain row-major f32 rows: n_pad x dimp].  The init arrays are the
+// accumulator start values of the coarse kernel: -|b|^2 / 2 resp. 0 for real rows, -inf for padding
+// rows.  The row-major copy serves the re-rank, which reads single rows (in the 32-row operand tiles
+// a row is 64 pieces of 16 bytes in 64 different cache lines).
 struct Bf16Shadow {
     const unsigned short* rows;
     const float* maxnorm_sq;
     const float* init_l2;
     const float* init_dot;
+    const float* rows_f32;
 };
 inline size_t bf16_rows_bytes(int n_pad, int dim) { return (size_t)n_pad * f32_dimp(dim) * 2; }
 inline size_t bf16_shadow_bytes(int n_pad, int dim)
 {
-    return bf16_rows_bytes(n_pad, dim) + 256 + 2 * ((size_t)n_pad + 64) * sizeof(float);
+    return bf16_rows_bytes(n_pad, dim) + 256 + 2 * ((size_t)n_pad + 64) * sizeof(float) +
+           (size_t)n_pad * f32_dimp(dim) * sizeof(float);
 }
 inline Bf16Shadow bf16_shadow_view(const void* base, int n_pad, int dim)
 {
@@ -66,6 +70,7 @@ inline Bf16Shadow bf16_shadow_view(const void* base, int n_pad, int dim)
     v.maxnorm_sq = reinterpret_cast<const float*>(p + bf16_rows_bytes(n_pad, dim));
     v.init_l2 = v.maxnorm_sq + 64;
     v.init_dot = v.init_l2 + n_pad + 64;
+    v.rows_f32 = v.init_dot + n_pad + 64;
     return v;
 }
 void launch_bf16_transform(const float* src, int n, int n_pad, int dim, bool dim_major, void* shadow_base,
@@ -79,16 +84,19 @@ struct CoarseProblem {
     const unsigned short* bfB;
     const float* initB;         // accumulator start values of B for pr.metric
     const float* maxnormB_sq;
+    const float* rowsA;         // plain row-major f32 rows (dimp floats each)
+    const float* rowsB;
     int32_t nstrips, nsplits, tiles_per_split;
     int32_t blk0;               // first workgroup of the coarse grid that belongs to this problem
-    int32_t rr_blk0;            // first workgroup of the re-rank grid
+    int32_t rr_blk0;            // unused (the re-rank grid is two-dimensional: query block x problem)
     int32_t reserved;
     int64_t part_off;           // first survivor sublist (sublists: [split][query][lane half])
     int64_t out_off;            // first output row in j1 / j2 / k1 / k2
 };
 
 struct CoarseTotals {
-    int coarse_blocks = 0, rerank_blocks = 0;
+    int coarse_blocks = 0;
+    int rerank_blocks = 0;   // query blocks of the largest problem (grid x of the re-rank)
     int64_t sublists = 0, out_rows = 0;
 };
 

@@ -583,6 +583,8 @@ CoarseProblem make_problem(const DescSet* A, const DescSet* B, int metric)
     p.bfB = sb.rows;
     p.initB = metric == VSM_METRIC_L2 ? sb.init_l2 : sb.init_dot;
     p.maxnormB_sq = sb.maxnorm_sq;
+    p.rowsA = sa.rows_f32;
+    p.rowsB = sb.rows_f32;
     return p;
 }
 
