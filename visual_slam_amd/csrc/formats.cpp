@@ -207,22 +207,74 @@ extern "C" int vsm_feature_txt_read(const char* path, float* xy, int cap)
 // =====================================================================================
 // match txt
 // =====================================================================================
+// "00".."99": two digits per table look-up
+struct DigitPairs {
+    char d[200];
+    DigitPairs()
+    {
+        for (int i = 0; i < 100; ++i) {
+            d[2 * i] = (char)('0' + i / 10);
+            d[2 * i + 1] = (char)('0' + i % 10);
+        }
+    }
+};
+static const DigitPairs kDigitPairs;
+
+// keypoint indices are small non-negative numbers: at most six digits on the short path
+static inline char* put_index(char* p, int32_t v)
+{
+    if (v < 0 || v >= 1000000) return put_int(p, v);
+    const unsigned u = (unsigned)v;
+    const char* t = kDigitPairs.d;
+    if (u < 100) {
+        if (u >= 10) *p++ = t[2 * u];
+        *p++ = t[2 * u + 1];
+        return p;
+    }
+    if (u < 10000) {
+        const unsigned hi = u / 100, lo = u % 100;
+        if (hi >= 10) *p++ = t[2 * hi];
+        *p++ = t[2 * hi + 1];
+        *p++ = t[2 * lo];
+        *p++ = t[2 * lo + 1];
+        return p;
+    }
+    const unsigned top = u / 10000, rest = u % 10000;
+    const unsigned hi = rest / 100, lo = rest % 100;
+    if (top >= 10) *p++ = t[2 * top];
+    *p++ = t[2 * top + 1];
+    *p++ = t[2 * hi];
+    *p++ = t[2 * hi + 1];
+    *p++ = t[2 * lo];
+    *p++ = t[2 * lo + 1];
+    return p;
+}
+
 static void matchtxt_format(std::string& rec, const char* name0, const char* name1,
                             const int32_t* idx0, const int32_t* idx1, int nm, int n0)
 {
-    rec.append(name0).append(" ").append(name1).append(" ");
-    char num[16];
-    rec.append(num, put_int(num, nm) - num);
-    rec.push_back('\n');
+    const size_t l0 = strlen(name0), l1 = strlen(name1);
+    const size_t start = rec.size();
+    // worst case: every entry 11 characters + separator, three line ends, the header
+    rec.resize(start + l0 + l1 + 16 + 2 * ((size_t)nm * 12 + 1));
+    char* const base = &rec[start];
+    char* p = base;
+    memcpy(p, name0, l0); p += l0;
+    *p++ = ' ';
+    memcpy(p, name1, l1); p += l1;
+    *p++ = ' ';
+    p = put_int(p, nm);
+    *p++ = '\n';
     for (int line = 0; line < 2; ++line) {
         const int32_t* v = line ? idx1 : idx0;
         for (int k = 0; k < nm; ++k) {
-            rec.append(num, put_int(num, v[k]) - num);
+            p = put_index(p, v[k]);
             // main.py:124-129: no separator after the entry of the last keypoint
-            if (idx0[k] != n0 - 1) rec.push_back(' ');
+            if (idx0[k] != n0 - 1) *p++ = ' ';
         }
-        rec.push_back('\n');
+        *p++ = '\n';
     }
+    rec.resize(start + (size_t)(p - base));
 }
 
 // Buffered writer for long runs: one open file, records appended in call order, flushed in

@@ -12,7 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -147,47 +150,105 @@ int main(int argc, char** argv)
     prm.min_score = -1e30f;
     prm.max_dist_sq_f = -1.0f;
 
-    std::vector<int32_t> ids, idx0, idx1;
-    std::vector<int64_t> off;
+    // The GPU side (this thread) and the writers (text formatting, .mat records) overlap: results of
+    // submission k are written by the worker while submission k + 1 runs.  Two result buffers.
+    struct Batch {
+        long long lo = 0;
+        int take = 0;
+        std::vector<int32_t> idx0, idx1;
+        std::vector<int64_t> off;
+    } batches[2];
+    std::mutex mu;
+    std::condition_variable cv;
+    int filled[2] = {0, 0};   // 0 = free for the GPU side, 1 = waiting for the writer
+    bool finished = false, write_failed = false;
+    std::string write_error;
+
+    std::thread writer([&]() {
+        for (int cur = 0;; cur ^= 1) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return filled[cur] == 1 || finished; });
+                if (filled[cur] != 1) return;
+            }
+            Batch& b = batches[cur];
+            for (int k = 0; k < b.take && !write_failed; ++k) {
+                const int ia = pairs[2 * (b.lo + k)], ib = pairs[2 * (b.lo + k) + 1];
+                const int nm = (int)(b.off[k + 1] - b.off[k]);
+                const std::string n0 = std::to_string(ia) + o.name_ext, n1 = std::to_string(ib) + o.name_ext;
+                if (vsm_matchtxt_write(tw, n0.c_str(), n1.c_str(), b.idx0.data() + b.off[k], b.idx1.data() + b.off[k], nm,
+                                       count[ia]) < 0) {
+                    write_failed = true;
+                    write_error = "write error on " + o.out;
+                }
+                if (o.write_mat && !write_failed) {
+                    const std::string p0 = o.sift_dir + "/" + std::to_string(ia), p1 = o.sift_dir + "/" + std::to_string(ib);
+                    const int rc = vsm_mat_write_pmatch(p0.c_str(), p1.c_str(), count[ia], count[ib], nm,
+                                                        b.idx0.data() + b.off[k], b.idx1.data() + b.off[k], o.num);
+                    if (rc < 0) {
+                        write_failed = true;
+                        write_error = "cannot write .mat for pair " + std::to_string(ia) + " " + std::to_string(ib);
+                    }
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                filled[cur] = 0;
+            }
+            cv.notify_all();
+        }
+    });
+
+    std::vector<int32_t> ids;
     long long total = 0;
-    for (long long lo = 0; lo < npairs; lo += o.batch) {
+    bool gpu_failed = false;
+    int cur = 0;
+    for (long long lo = 0; lo < npairs && !gpu_failed; lo += o.batch, cur ^= 1) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return filled[cur] == 0; });
+        }
+        if (write_failed) break;
+        Batch& b = batches[cur];
         const int take = (int)std::min<long long>(o.batch, npairs - lo);
         ids.resize((size_t)take * 2);
         size_t cap = 1;
         for (int k = 0; k < take; ++k) {
-            const int a = pairs[2 * (lo + k)], b = pairs[2 * (lo + k) + 1];
-            ids[2 * k] = set_id[a];
-            ids[2 * k + 1] = set_id[b];
-            cap += (size_t)count[a];
+            const int ia = pairs[2 * (lo + k)], ib = pairs[2 * (lo + k) + 1];
+            ids[2 * k] = set_id[ia];
+            ids[2 * k + 1] = set_id[ib];
+            cap += (size_t)count[ia];
         }
-        idx0.resize(cap);
-        idx1.resize(cap);
-        off.resize((size_t)take + 1);
-        const long long got = vsm_match_pairs(ctx, ids.data(), take, &prm, VSM_METRIC_L2, off.data(),
-                                              idx0.data(), idx1.data(), (long long)cap);
+        b.lo = lo;
+        b.take = take;
+        b.idx0.resize(cap);
+        b.idx1.resize(cap);
+        b.off.resize((size_t)take + 1);
+        const long long got = vsm_match_pairs(ctx, ids.data(), take, &prm, VSM_METRIC_L2, b.off.data(),
+                                              b.idx0.data(), b.idx1.data(), (long long)cap);
         if (got < 0) {
             fprintf(stderr, "vsm_match_pairs: %s\n", vsm_last_error(ctx));
-            return 1;
+            gpu_failed = true;
+            break;
         }
         total += got;
-        for (int k = 0; k < take; ++k) {
-            const int a = pairs[2 * (lo + k)], b = pairs[2 * (lo + k) + 1];
-            const int nm = (int)(off[k + 1] - off[k]);
-            const std::string n0 = std::to_string(a) + o.name_ext, n1 = std::to_string(b) + o.name_ext;
-            if (vsm_matchtxt_write(tw, n0.c_str(), n1.c_str(), idx0.data() + off[k], idx1.data() + off[k], nm, count[a]) < 0) {
-                fprintf(stderr, "write error on %s\n", o.out.c_str());
-                return 1;
-            }
-            if (o.write_mat) {
-                const std::string p0 = o.sift_dir + "/" + std::to_string(a), p1 = o.sift_dir + "/" + std::to_string(b);
-                const int rc = vsm_mat_write_pmatch(p0.c_str(), p1.c_str(), count[a], count[b], nm,
-                                                    idx0.data() + off[k], idx1.data() + off[k], o.num);
-                if (rc < 0) {
-                    fprintf(stderr, "cannot write .mat for pair %d %d (%d)\n", a, b, rc);
-                    return 1;
-                }
-            }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            filled[cur] = 1;
         }
+        cv.notify_all();
+    }
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return filled[0] == 0 && filled[1] == 0; });
+        finished = true;
+    }
+    cv.notify_all();
+    writer.join();
+    if (gpu_failed) return 1;
+    if (write_failed) {
+        fprintf(stderr, "%s\n", write_error.c_str());
+        return 1;
     }
     if (vsm_matchtxt_close(tw) != VSM_OK) {
         fprintf(stderr, "write error on %s\n", o.out.c_str());
