@@ -23,6 +23,7 @@ namespace {
 struct Options {
     std::string sift_dir, out = "matching.txt", name_ext = ".jpg", sift_ext = ".sift";
     int num = 0, device = 0, batch = 2048;
+    int shard = 0, nshards = 1;
     bool exhaustive = true, mutual = true, write_mat = false, append = false;
     int consecutive = 3;
     std::vector<int32_t> discrete{7, 15};
@@ -44,7 +45,10 @@ void usage()
             "  --no-mutual           skip the mutual-nearest-neighbour check\n"
             "  --mat                 also write <DIR>/<i>.mat putative-match records\n"
             "  --name-ext EXT        image-name suffix in the match txt (default .jpg)\n"
-            "  --device N, --batch P (pairs per GPU submission, default 2048)\n");
+            "  --device N, --batch P (pairs per GPU submission, default 2048)\n"
+            "  --shard R/W           match only the R-th of W contiguous slices of the pair list (one process\n"
+            "                        per GPU); with W > 1 the text goes to FILE.partR: concatenating the parts in\n"
+            "                        order gives the file of an unsharded run\n");
 }
 
 bool parse(int argc, char** argv, Options& o)
@@ -83,6 +87,13 @@ bool parse(int argc, char** argv, Options& o)
         else if (a == "--name-ext") { if (!(v = next("--name-ext"))) return false; o.name_ext = v; }
         else if (a == "--device") { if (!(v = next("--device"))) return false; o.device = atoi(v); }
         else if (a == "--batch") { if (!(v = next("--batch"))) return false; o.batch = atoi(v); }
+        else if (a == "--shard") {
+            if (!(v = next("--shard"))) return false;
+            if (sscanf(v, "%d/%d", &o.shard, &o.nshards) != 2 || o.nshards < 1 || o.shard < 0 || o.shard >= o.nshards) {
+                fprintf(stderr, "--shard wants R/W with 0 <= R < W\n");
+                return false;
+            }
+        }
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
     }
     return !o.sift_dir.empty() && o.num > 0 && o.batch > 0;
@@ -135,6 +146,16 @@ int main(int argc, char** argv)
         npairs = vsm_image_pairs(o.num, o.consecutive, o.discrete.data(), (int)o.discrete.size(), nullptr, 0);
         pairs.resize((size_t)npairs * 2 + 2);
         vsm_image_pairs(o.num, o.consecutive, o.discrete.data(), (int)o.discrete.size(), pairs.data(), (int)npairs);
+    }
+
+    // this process's slice of the pair list
+    if (o.nshards > 1) {
+        const long long per = (npairs + o.nshards - 1) / o.nshards;
+        const long long lo = std::min<long long>(npairs, per * o.shard), hi = std::min<long long>(npairs, lo + per);
+        pairs.erase(pairs.begin(), pairs.begin() + 2 * lo);
+        pairs.resize((size_t)(hi - lo) * 2 + 2);
+        npairs = hi - lo;
+        if (o.out != "/dev/null") o.out += ".part" + std::to_string(o.shard);
     }
 
     vsm_txtwriter* tw = vsm_matchtxt_open(o.out.c_str(), o.append ? 0 : 1);
