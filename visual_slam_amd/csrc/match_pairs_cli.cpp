@@ -22,7 +22,7 @@ namespace {
 
 struct Options {
     std::string sift_dir, out = "matching.txt", name_ext = ".jpg", sift_ext = ".sift";
-    int num = 0, device = 0, batch = 2048;
+    int num = 0, device = 0, batch = 8192;
     int shard = 0, nshards = 1;
     bool exhaustive = true, mutual = true, write_mat = false, append = false;
     int consecutive = 3;
@@ -45,7 +45,7 @@ void usage()
             "  --no-mutual           skip the mutual-nearest-neighbour check\n"
             "  --mat                 also write <DIR>/<i>.mat putative-match records\n"
             "  --name-ext EXT        image-name suffix in the match txt (default .jpg)\n"
-            "  --device N, --batch P (pairs per GPU submission, default 2048)\n"
+            "  --device N, --batch P (pairs per library call, default 8192)\n"
             "  --shard R/W           match only the R-th of W contiguous slices of the pair list (one process\n"
             "                        per GPU); with W > 1 the text goes to FILE.partR: concatenating the parts in\n"
             "                        order gives the file of an unsharded run\n");
@@ -115,25 +115,46 @@ int main(int argc, char** argv)
     }
     const auto t_start = std::chrono::steady_clock::now();
 
-    // ---- load and upload every image's descriptors once
+    // ---- load and upload every image's descriptors once: files are read by a few threads, 256 at a
+    // time, and uploaded in order by this one
     std::vector<int> set_id(o.num, -1), count(o.num, 0);
-    std::vector<uint8_t> des;
-    for (int i = 0; i < o.num; ++i) {
-        const std::string path = o.sift_dir + "/" + std::to_string(i) + o.sift_ext;
-        int np = 0, nloc = 0;
-        if (!vsm_sift_read(path.c_str(), nullptr, nullptr, 0, &np, &nloc)) np = 0;  // unreadable or empty
-        des.resize((size_t)np * VSM_DESC_DIM_U8 + 1);
-        if (np > 0 && !vsm_sift_read(path.c_str(), nullptr, des.data(), np, nullptr, nullptr)) {
-            fprintf(stderr, "short read: %s\n", path.c_str());
-            return 1;
-        }
-        count[i] = np;
-        set_id[i] = vsm_upload_u8(ctx, des.data(), np);
-        if (set_id[i] < 0) {
-            fprintf(stderr, "upload %s: %s\n", path.c_str(), vsm_last_error(ctx));
-            return 1;
+    {
+        const int kChunk = 256;
+        const int nthreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        std::vector<std::vector<uint8_t>> des(kChunk);
+        std::vector<int> np(kChunk), bad(kChunk);
+        for (int base = 0; base < o.num; base += kChunk) {
+            const int m = std::min(kChunk, o.num - base);
+            std::vector<std::thread> readers;
+            for (int t = 0; t < nthreads; ++t)
+                readers.emplace_back([&, t]() {
+                    for (int k = t; k < m; k += nthreads) {
+                        const std::string path = o.sift_dir + "/" + std::to_string(base + k) + o.sift_ext;
+                        int n = 0, nloc = 0;
+                        if (!vsm_sift_read(path.c_str(), nullptr, nullptr, 0, &n, &nloc)) n = 0;  // unreadable or empty
+                        des[k].resize((size_t)n * VSM_DESC_DIM_U8 + 1);
+                        bad[k] = n > 0 && !vsm_sift_read(path.c_str(), nullptr, des[k].data(), n, nullptr, nullptr);
+                        np[k] = n;
+                    }
+                });
+            for (auto& r : readers) r.join();
+            for (int k = 0; k < m; ++k) {
+                const int i = base + k;
+                if (bad[k]) {
+                    fprintf(stderr, "short read: %s/%d%s\n", o.sift_dir.c_str(), i, o.sift_ext.c_str());
+                    return 1;
+                }
+                count[i] = np[k];
+                set_id[i] = vsm_upload_u8(ctx, des[k].data(), np[k]);
+                if (set_id[i] < 0) {
+                    fprintf(stderr, "upload %d%s: %s\n", i, o.sift_ext.c_str(), vsm_last_error(ctx));
+                    return 1;
+                }
+            }
         }
     }
+
+    const double load_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 
     // ---- pair list
     std::vector<int32_t> pairs;
@@ -276,8 +297,8 @@ int main(int argc, char** argv)
         return 1;
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-    fprintf(stderr, "%d images, %lld pairs, %lld matches, %.3f s (%.0f pairs/s)\n", o.num, npairs, total, secs,
-            npairs / secs);
+    fprintf(stderr, "%d images, %lld pairs, %lld matches, %.3f s (%.0f pairs/s); reading + upload %.3f s, matching + writing %.3f s\n",
+            o.num, npairs, total, secs, npairs / secs, load_secs, secs - load_secs);
     vsm_destroy(ctx);
     return 0;
 }

@@ -86,11 +86,21 @@ struct vsm_ctx {
     std::vector<DescSet> sets;
     // workspace (grow-only)
     DevBuf d_pairs, d_items, d_rr1, d_rrj, d_rr2, d_colpart, d_cand;
-    DevBuf d_slot0, d_slot1, d_slotd, d_counts, d_offsets, d_tight0, d_tight1;
+    DevBuf d_slot0, d_slot1, d_slotd, d_counts;
     DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_flag, d_probs, d_refs;
     // float sets: 0 = bf16 coarse pass + exact re-rank (exact kernel when a survivor list overflows), 1 = exact kernel only
     int f32_mode = 0, last_f32_path = -1;
-    HostBuf h_pairs, h_items, h_small, h_probs, h_refs;
+    HostBuf h_small, h_probs, h_refs;
+    // Two sets of per-submission staging and result buffers, so that vsm_match_pairs can queue
+    // submission k + 1 while the match lists of submission k travel to the host on copy_stream.
+    struct ResultSlot {
+        DevBuf d_offsets, d_tight0, d_tight1;
+        HostBuf h_pairs, h_items, h_off;
+        hipEvent_t packed = nullptr;
+    } slots[2];
+    int rs = 0;   // slot the next submission uses / the last one used
+    ResultSlot& R() { return slots[rs]; }
+    hipStream_t copy_stream = nullptr;
     // last device-resident result
     int last_npairs = 0;
     long long last_total = 0;
@@ -204,8 +214,8 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     const int npairs = (int)pl.pairs.size();
     const int nitems = (int)pl.items.size();
     const int nvitems = rule.mutual ? (int)pl.vitems.size() : 0;
-    HIPCHK(c, c->h_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
-    HIPCHK(c, c->h_items.ensure(sizeof(SiftItem) * std::max(nitems + nvitems, 1)));
+    HIPCHK(c, c->R().h_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
+    HIPCHK(c, c->R().h_items.ensure(sizeof(SiftItem) * std::max(nitems + nvitems, 1)));
     HIPCHK(c, c->d_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
     HIPCHK(c, c->d_items.ensure(sizeof(SiftItem) * std::max(nitems + nvitems, 1)));
     const size_t rows = std::max<size_t>(pl.rows, 1);
@@ -218,10 +228,10 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     HIPCHK(c, c->d_slot1.ensure(out0 * 4));
     if (o.want_dist) HIPCHK(c, c->d_slotd.ensure(out0 * 4));
     HIPCHK(c, c->d_counts.ensure(sizeof(int32_t) * std::max(npairs, 1)));
-    HIPCHK(c, c->d_offsets.ensure(sizeof(int64_t) * (npairs + 1)));
+    HIPCHK(c, c->R().d_offsets.ensure(sizeof(int64_t) * (npairs + 1)));
     if (o.want_pack) {
-        HIPCHK(c, c->d_tight0.ensure(out0 * 4));
-        HIPCHK(c, c->d_tight1.ensure(out0 * 4));
+        HIPCHK(c, c->R().d_tight0.ensure(out0 * 4));
+        HIPCHK(c, c->R().d_tight1.ensure(out0 * 4));
     }
     if (o.want_dense) {
         HIPCHK(c, c->d_dense0.ensure(out0 * 4));
@@ -234,12 +244,12 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     }
     // the pinned staging buffers may still feed a previous copy
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (npairs) memcpy(c->h_pairs.p, pl.pairs.data(), sizeof(SiftPair) * npairs);
-    if (nitems) memcpy(c->h_items.p, pl.items.data(), sizeof(SiftItem) * nitems);
-    if (nvitems) memcpy(c->h_items.as<SiftItem>() + nitems, pl.vitems.data(), sizeof(SiftItem) * nvitems);
-    if (npairs) HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->h_pairs.p, sizeof(SiftPair) * npairs, hipMemcpyHostToDevice, c->stream));
+    if (npairs) memcpy(c->R().h_pairs.p, pl.pairs.data(), sizeof(SiftPair) * npairs);
+    if (nitems) memcpy(c->R().h_items.p, pl.items.data(), sizeof(SiftItem) * nitems);
+    if (nvitems) memcpy(c->R().h_items.as<SiftItem>() + nitems, pl.vitems.data(), sizeof(SiftItem) * nvitems);
+    if (npairs) HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->R().h_pairs.p, sizeof(SiftPair) * npairs, hipMemcpyHostToDevice, c->stream));
     if (nitems + nvitems)
-        HIPCHK(c, hipMemcpyAsync(c->d_items.p, c->h_items.p, sizeof(SiftItem) * (nitems + nvitems), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_items.p, c->R().h_items.p, sizeof(SiftItem) * (nitems + nvitems), hipMemcpyHostToDevice, c->stream));
 
     c->ev_valid = false;
     c->ev_verify_valid = false;
@@ -286,8 +296,8 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
         launch_sift_confirm(c->d_pairs.as<SiftPair>(), npairs, cand, nvitems ? 1 : 0, out, c->stream);
         if (o.want_pack)
             launch_pack(c->d_pairs.as<SiftPair>(), npairs, c->d_counts.as<int32_t>(),
-                        c->d_offsets.as<int64_t>(), c->d_slot0.as<int32_t>(), c->d_slot1.as<int32_t>(),
-                        c->d_tight0.as<int32_t>(), c->d_tight1.as<int32_t>(), c->stream);
+                        c->R().d_offsets.as<int64_t>(), c->d_slot0.as<int32_t>(), c->d_slot1.as<int32_t>(),
+                        c->R().d_tight0.as<int32_t>(), c->R().d_tight1.as<int32_t>(), c->stream);
     }
     HIPCHK(c, hipGetLastError());
     return VSM_OK;
@@ -348,7 +358,10 @@ extern "C" vsm_ctx* vsm_create(int device)
     c->device = device;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev2)) != hipSuccess || (e = hipEventCreate(&c->ev3)) != hipSuccess) {
+        (e = hipEventCreate(&c->ev2)) != hipSuccess || (e = hipEventCreate(&c->ev3)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->slots[0].packed, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->slots[1].packed, hipEventDisableTiming)) != hipSuccess) {
         fail(nullptr, VSM_ENODEV, "stream/event creation: %s", hipGetErrorString(e));
         delete c;
         return nullptr;
@@ -361,19 +374,27 @@ extern "C" void vsm_destroy(vsm_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (auto& s : c->sets) {
         if (s.frag) (void)hipFree(s.frag);
         if (s.nrm) (void)hipFree(s.nrm);
         if (s.shadow) (void)hipFree(s.shadow);
     }
     DevBuf* bufs[] = {&c->d_pairs, &c->d_items, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart, &c->d_cand,
-                      &c->d_slot0, &c->d_slot1, &c->d_slotd, &c->d_counts, &c->d_offsets,
-                      &c->d_tight0, &c->d_tight1, &c->d_dense0, &c->d_dense1,
+                      &c->d_slot0, &c->d_slot1, &c->d_slotd, &c->d_counts, &c->d_dense0, &c->d_dense1,
                       &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage, &c->d_coarse, &c->d_flag,
                       &c->d_probs, &c->d_refs};
     for (DevBuf* b : bufs) b->release();
-    c->h_pairs.release();
-    c->h_items.release();
+    for (auto& r : c->slots) {
+        r.d_offsets.release();
+        r.d_tight0.release();
+        r.d_tight1.release();
+        r.h_pairs.release();
+        r.h_items.release();
+        r.h_off.release();
+        if (r.packed) (void)hipEventDestroy(r.packed);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->h_small.release();
     c->h_probs.release();
     c->h_refs.release();
@@ -794,7 +815,7 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
         if (rf.fwd_off >= 0) rf.fwd_off = pl.probs[rf.fwd_off].out_off;
         if (rf.bwd_off >= 0) rf.bwd_off = pl.probs[rf.bwd_off].out_off;
     }
-    HIPCHK(c, c->h_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
+    HIPCHK(c, c->R().h_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
     HIPCHK(c, c->d_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
     HIPCHK(c, c->h_refs.ensure(sizeof(F32PairRef) * std::max(npairs, 1)));
     HIPCHK(c, c->d_refs.ensure(sizeof(F32PairRef) * std::max(npairs, 1)));
@@ -803,22 +824,22 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     HIPCHK(c, c->d_slot1.ensure(n0 * 4));
     if (o.want_dist) HIPCHK(c, c->d_slotd.ensure(n0 * 4));
     HIPCHK(c, c->d_counts.ensure(sizeof(int32_t) * std::max(npairs, 1)));
-    HIPCHK(c, c->d_offsets.ensure(sizeof(int64_t) * (npairs + 1)));
+    HIPCHK(c, c->R().d_offsets.ensure(sizeof(int64_t) * (npairs + 1)));
     if (o.want_pack) {
-        HIPCHK(c, c->d_tight0.ensure(n0 * 4));
-        HIPCHK(c, c->d_tight1.ensure(n0 * 4));
+        HIPCHK(c, c->R().d_tight0.ensure(n0 * 4));
+        HIPCHK(c, c->R().d_tight1.ensure(n0 * 4));
     }
     if (o.want_dense) {
         HIPCHK(c, c->d_dense0.ensure(n0 * 4));
         HIPCHK(c, c->d_dense1.ensure(n1 * 4));
     }
     if (npairs == 0) {
-        HIPCHK(c, hipMemsetAsync(c->d_offsets.p, 0, sizeof(int64_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->R().d_offsets.p, 0, sizeof(int64_t), c->stream));
         return VSM_OK;
     }
-    memcpy(c->h_pairs.p, pl.pairs.data(), sizeof(SiftPair) * npairs);
+    memcpy(c->R().h_pairs.p, pl.pairs.data(), sizeof(SiftPair) * npairs);
     memcpy(c->h_refs.p, pl.refs.data(), sizeof(F32PairRef) * npairs);
-    HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->h_pairs.p, sizeof(SiftPair) * npairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->R().h_pairs.p, sizeof(SiftPair) * npairs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_refs.p, c->h_refs.p, sizeof(F32PairRef) * npairs, hipMemcpyHostToDevice, c->stream));
     SiftOutputs out{};
     out.slot_i0 = c->d_slot0.as<int32_t>();
@@ -830,8 +851,8 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     launch_f32_accept(c->d_pairs.as<SiftPair>(), c->d_refs.as<F32PairRef>(), npairs, rule, c->d_knnj.as<int32_t>(),
                       c->d_knn1.as<float>(), c->d_knn2.as<float>(), out, c->stream);
     if (o.want_pack)
-        launch_pack(c->d_pairs.as<SiftPair>(), npairs, out.counts, c->d_offsets.as<int64_t>(), out.slot_i0, out.slot_i1,
-                    c->d_tight0.as<int32_t>(), c->d_tight1.as<int32_t>(), c->stream);
+        launch_pack(c->d_pairs.as<SiftPair>(), npairs, out.counts, c->R().d_offsets.as<int64_t>(), out.slot_i0, out.slot_i1,
+                    c->R().d_tight0.as<int32_t>(), c->R().d_tight1.as<int32_t>(), c->stream);
     HIPCHK(c, hipGetLastError());
     return VSM_OK;
 }
@@ -887,13 +908,13 @@ long long f32_pairs_slow(vsm_ctx* c, const int32_t* pairs, int npairs, const vsm
     }
     c->f32_mode = saved;
     const size_t tot = i0.size();
-    HIPCHK(c, c->d_offsets.ensure(sizeof(int64_t) * (npairs + 1)));
-    HIPCHK(c, c->d_tight0.ensure(std::max<size_t>(tot, 1) * 4));
-    HIPCHK(c, c->d_tight1.ensure(std::max<size_t>(tot, 1) * 4));
-    HIPCHK(c, hipMemcpy(c->d_offsets.p, off.data(), sizeof(int64_t) * (npairs + 1), hipMemcpyHostToDevice));
+    HIPCHK(c, c->R().d_offsets.ensure(sizeof(int64_t) * (npairs + 1)));
+    HIPCHK(c, c->R().d_tight0.ensure(std::max<size_t>(tot, 1) * 4));
+    HIPCHK(c, c->R().d_tight1.ensure(std::max<size_t>(tot, 1) * 4));
+    HIPCHK(c, hipMemcpy(c->R().d_offsets.p, off.data(), sizeof(int64_t) * (npairs + 1), hipMemcpyHostToDevice));
     if (tot) {
-        HIPCHK(c, hipMemcpy(c->d_tight0.p, i0.data(), tot * 4, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->d_tight1.p, i1.data(), tot * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->R().d_tight0.p, i0.data(), tot * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->R().d_tight1.p, i1.data(), tot * 4, hipMemcpyHostToDevice));
     }
     return (long long)tot;
 }
@@ -933,7 +954,7 @@ extern "C" long long vsm_match_pairs_device(vsm_ctx* c, const int32_t* pairs, in
     long long* tot = c->h_small.as<long long>();
     *tot = 0;
     if (npairs)
-        HIPCHK(c, hipMemcpyAsync(tot, c->d_offsets.as<int64_t>() + npairs, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(tot, c->R().d_offsets.as<int64_t>() + npairs, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->last_npairs = npairs;
     c->last_total = *tot;
@@ -947,7 +968,7 @@ extern "C" long long vsm_fetch_matches(vsm_ctx* c, int64_t* offsets, int32_t* id
     const long long tot = c->last_total;
     if (offsets) {
         if (c->last_npairs)
-            HIPCHK(c, hipMemcpyAsync(offsets, c->d_offsets.p, sizeof(int64_t) * (c->last_npairs + 1), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(offsets, c->R().d_offsets.p, sizeof(int64_t) * (c->last_npairs + 1), hipMemcpyDeviceToHost, c->stream));
         else
             offsets[0] = 0;
     }
@@ -956,8 +977,8 @@ extern "C" long long vsm_fetch_matches(vsm_ctx* c, int64_t* offsets, int32_t* id
         return fail(c, VSM_ECAP, "%lld matches do not fit a buffer of %lld", tot, cap);
     }
     if (tot > 0) {
-        if (idx0) HIPCHK(c, hipMemcpyAsync(idx0, c->d_tight0.p, sizeof(int32_t) * tot, hipMemcpyDeviceToHost, c->stream));
-        if (idx1) HIPCHK(c, hipMemcpyAsync(idx1, c->d_tight1.p, sizeof(int32_t) * tot, hipMemcpyDeviceToHost, c->stream));
+        if (idx0) HIPCHK(c, hipMemcpyAsync(idx0, c->R().d_tight0.p, sizeof(int32_t) * tot, hipMemcpyDeviceToHost, c->stream));
+        if (idx1) HIPCHK(c, hipMemcpyAsync(idx1, c->R().d_tight1.p, sizeof(int32_t) * tot, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return tot;
@@ -970,11 +991,11 @@ extern "C" long long vsm_match_pairs(vsm_ctx* c, const int32_t* pairs, int npair
     if (npairs < 0 || (npairs > 0 && !pairs) || !offsets) return fail(c, VSM_EINVAL, "bad pair list or offsets buffer");
     int rc = check_params(c, p);
     if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
     // cut the list into submissions that fit the scratch budget
-    long long total = 0;
-    int done = 0;
-    offsets[0] = 0;
-    while (done < npairs) {
+    std::vector<int> cuts{0};
+    while (cuts.back() < npairs) {
+        const int done = cuts.back();
         size_t scratch = 0;
         int take = 0;
         while (done + take < npairs) {
@@ -989,17 +1010,85 @@ extern "C" long long vsm_match_pairs(vsm_ctx* c, const int32_t* pairs, int npair
             scratch += need;
             ++take;
         }
-        const long long got = vsm_match_pairs_device(c, pairs + 2 * (size_t)done, take, p, metric);
-        if (got < 0) return got;
-        if (total + got > cap) return fail(c, VSM_ECAP, "more than %lld matches", cap);
-        std::vector<int64_t> off(take + 1);
-        const long long f = vsm_fetch_matches(c, off.data(), idx0 ? idx0 + total : nullptr,
-                                              idx1 ? idx1 + total : nullptr, cap - total);
-        if (f < 0) return f;
+        cuts.push_back(done + take);
+    }
+    const int nsub = (int)cuts.size() - 1;
+    offsets[0] = 0;
+    long long total = 0;
+    const DescSet* first = npairs > 0 ? get_set(c, pairs[0]) : nullptr;
+    if (!first || first->kind != SET_U8) {
+        // float pairs (and the empty list): one submission at a time
+        for (int k = 0; k < nsub; ++k) {
+            const int done = cuts[k], take = cuts[k + 1] - cuts[k];
+            const long long got = vsm_match_pairs_device(c, pairs + 2 * (size_t)done, take, p, metric);
+            if (got < 0) return got;
+            if (total + got > cap) return fail(c, VSM_ECAP, "more than %lld matches", cap);
+            std::vector<int64_t> off(take + 1);
+            const long long f = vsm_fetch_matches(c, off.data(), idx0 ? idx0 + total : nullptr,
+                                                  idx1 ? idx1 + total : nullptr, cap - total);
+            if (f < 0) return f;
+            for (int i = 0; i <= take; ++i) offsets[done + i] = total + off[i];
+            total += got;
+        }
+        return total;
+    }
+    // u8 pairs: submission k + 1 is queued before the lists of submission k are fetched, and the
+    // fetch runs on the copy stream, so the compute stream never waits for the host
+    const MatchRule rule = make_rule(p);
+    auto enqueue = [&](int k) -> int {
+        c->rs = k & 1;
+        Plan pl;
+        int r = plan_u8(c, pairs + 2 * (size_t)cuts[k], cuts[k + 1] - cuts[k], pl);
+        if (r) return r;
+        RunOpts o;
+        if ((r = run_u8(c, pl, rule, o)) != VSM_OK) return r;
+        HIPCHK(c, hipEventRecord(c->R().packed, c->stream));
+        return VSM_OK;
+    };
+    auto drain = [&]() {   // after a failure: nothing of this call may still be running
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->copy_stream);
+    };
+    if (nsub > 0 && (rc = enqueue(0)) != VSM_OK) return rc;
+    for (int k = 0; k < nsub; ++k) {
+        if (k + 1 < nsub && (rc = enqueue(k + 1)) != VSM_OK) {
+            drain();
+            return rc;
+        }
+        c->rs = k & 1;
+        vsm_ctx::ResultSlot& R = c->R();
+        const int done = cuts[k], take = cuts[k + 1] - cuts[k];
+        hipError_t e = hipEventSynchronize(R.packed);
+        if (e == hipSuccess) e = R.h_off.ensure(sizeof(int64_t) * (take + 1));
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(R.h_off.p, R.d_offsets.p, sizeof(int64_t) * (take + 1), hipMemcpyDeviceToHost, c->copy_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+        if (e != hipSuccess) {
+            drain();
+            return fail(c, VSM_ENODEV, "fetching match offsets: %s", hipGetErrorString(e));
+        }
+        const int64_t* off = R.h_off.as<int64_t>();
+        const long long got = off[take];
+        if (total + got > cap) {
+            drain();
+            return fail(c, VSM_ECAP, "more than %lld matches", cap);
+        }
+        if (got > 0) {
+            if (idx0) e = hipMemcpyAsync(idx0 + total, R.d_tight0.p, sizeof(int32_t) * got, hipMemcpyDeviceToHost, c->copy_stream);
+            if (e == hipSuccess && idx1)
+                e = hipMemcpyAsync(idx1 + total, R.d_tight1.p, sizeof(int32_t) * got, hipMemcpyDeviceToHost, c->copy_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+            if (e != hipSuccess) {
+                drain();
+                return fail(c, VSM_ENODEV, "fetching match lists: %s", hipGetErrorString(e));
+            }
+        }
         for (int i = 0; i <= take; ++i) offsets[done + i] = total + off[i];
         total += got;
-        done += take;
     }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->last_npairs = nsub > 0 ? cuts[nsub] - cuts[nsub - 1] : 0;
+    c->last_total = nsub > 0 ? c->R().h_off.as<int64_t>()[c->last_npairs] : 0;
     return total;
 }
 
