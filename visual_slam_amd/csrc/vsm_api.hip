@@ -784,6 +784,8 @@ int plan_f32(vsm_ctx* c, const int32_t* pairs, int npairs, int metric, bool mutu
         pl.refs[p] = rf;
     }
     if (pl.dim == 0) pl.dim = 256;
+    if (pl.probs.size() > 65535)   // one grid row of the re-rank kernel per search
+        return fail(c, VSM_EINVAL, "%zu searches in one submission (limit 65535); submit fewer pairs per call", pl.probs.size());
     return VSM_OK;
 }
 
