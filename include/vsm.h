@@ -110,6 +110,10 @@ int vsm_match_pair_dense(vsm_ctx* ctx, int set0, int set1, const vsm_params* p, 
 long long vsm_match_pairs(vsm_ctx* ctx, const int32_t* pairs, int npairs, const vsm_params* p,
                           int metric, int64_t* offsets, int32_t* idx0, int32_t* idx1,
                           long long cap);
+/* Device scratch vsm_match_pairs may use per submission (default 8 GiB, at least 1 MiB): it cuts
+ * the pair list into submissions of about half that and keeps two of them in flight (the next one is
+ * queued before the lists of the last one are fetched).  A single pair is never cut. */
+int vsm_set_scratch_budget(vsm_ctx* ctx, long long bytes);
 /* Same work, results left on the device; returns the total match count.  Fetch with
  * vsm_fetch_matches before the next submission on this context. */
 long long vsm_match_pairs_device(vsm_ctx* ctx, const int32_t* pairs, int npairs,

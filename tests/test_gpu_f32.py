@@ -233,3 +233,34 @@ def test_float_pairs_in_one_submission(matcher, metric, ratio, mutual):
     assert off[-1] == total and total > 500
     for sid in ids:
         matcher.release(sid)
+
+
+def test_database_query_full_size_both_paths_agree(matcher, f32_mode):
+    """16384 queries against 1 M rows (the localisation-query shape): the bf16 + re-rank path and the
+    f32 matrix-core kernel must return the same bits; a 64-query sample is checked against the oracle."""
+    if f32_mode != vsm.F32_FAST_EXACT:
+        pytest.skip("one comparison covers both paths")
+    rng = np.random.default_rng(51)
+    q = synth.unit_f32(16384, 256, rng)
+    db = rng.standard_normal((1000000, 256), dtype=np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    db[777777] = q[5]
+    db[12] = q[5]
+    sq, sd = matcher.upload_f32(q), matcher.upload_f32(db)
+    try:
+        fast = matcher.knn2(sq, sd, vsm.METRIC_L2, want_idx2=True)
+        assert matcher.last_f32_path() == vsm.F32_FAST_EXACT
+        matcher.set_f32_mode(vsm.F32_MFMA_F32)
+        exact = matcher.knn2(sq, sd, vsm.METRIC_L2, want_idx2=True)
+        assert matcher.last_f32_path() == vsm.F32_MFMA_F32
+        for f, e in zip(fast, exact):
+            np.testing.assert_array_equal(f, e)
+        assert fast[0][5] == 12 and fast[1][5] == 777777
+        oi, ok1, ok2 = orc.knn2_f32(q[:64], db, orc.METRIC_L2)
+        np.testing.assert_array_equal(fast[0][:64], oi)
+        np.testing.assert_array_equal(fast[2][:64], ok1)
+        np.testing.assert_array_equal(fast[3][:64], ok2)
+    finally:
+        matcher.set_f32_mode(vsm.F32_FAST_EXACT)
+        matcher.release(sq)
+        matcher.release(sd)

@@ -132,3 +132,61 @@ def test_batch_of_pairs(matcher):
         np.testing.assert_array_equal(i1[off[k]:off[k + 1]], o1)
     for s in ids:
         matcher.release(s)
+
+
+def test_many_submissions_in_flight(matcher):
+    """A small scratch budget cuts the pair list into many submissions, which match_pairs keeps two at a
+    time in flight: the lists must come back in pair order all the same."""
+    rng = np.random.default_rng(13)
+    sizes = [900, 513, 0, 1300, 64, 2100, 777, 1]
+    base = synth.sift_like(500, rng)
+    imgs = []
+    for n in sizes:
+        x = synth.sift_like(n, rng)
+        k = min(n, 500) // 2
+        if k:
+            x[rng.choice(n, k, replace=False)] = np.clip(
+                base[rng.choice(500, k, replace=False)].astype(np.int32) + rng.integers(-4, 5, (k, 128)), 0, 255).astype(np.uint8)
+        imgs.append(x)
+    ids = [matcher.upload_u8(x) for x in imgs]
+    pairs = [(i, j) for i in range(len(ids)) for j in range(len(ids)) if i != j]
+    matcher.set_scratch_budget(1 << 20)
+    try:
+        off, i0, i1 = matcher.match_pairs([[ids[i], ids[j]] for i, j in pairs])
+    finally:
+        matcher.set_scratch_budget(8 << 30)
+    assert off[0] == 0 and off[-1] == len(i0)
+    for k, (i, j) in enumerate(pairs):
+        o0, o1, _ = orc.match_u8(imgs[i], imgs[j], orc.params((4, 5), True))
+        np.testing.assert_array_equal(i0[off[k]:off[k + 1]], o0)
+        np.testing.assert_array_equal(i1[off[k]:off[k + 1]], o1)
+    for s in ids:
+        matcher.release(s)
+
+
+def test_full_size_pair_8192(matcher):
+    """The benchmark's pair shape, checked element for element."""
+    a, b = synth.sift_pair(8192, 8192, seed=14)
+    assert _check_pair(matcher, a, b) > 500
+
+
+def test_stress_pair_65536(matcher):
+    """65536 x 65536 (eight 8192-row chunks per query strip), element for element against the oracle."""
+    a, b = synth.sift_pair(65536, 65536, seed=15)
+    b[60000] = a[123]      # duplicates far apart: ties across chunks
+    b[70] = a[123]
+    s0, s1 = matcher.upload_u8(a), matcher.upload_u8(b)
+    try:
+        gi, gd1, gd2 = matcher.knn2(s0, s1)
+        oi, od1, od2 = orc.knn2_u8(a, b)
+        np.testing.assert_array_equal(gi, oi)
+        np.testing.assert_array_equal(gd1, od1)
+        np.testing.assert_array_equal(gd2, od2)
+        g0, g1 = matcher.match_pair(s0, s1, ratio=0.8, mutual=True)
+        o0, o1, _ = orc.match_u8(a, b, orc.params((4, 5), True))
+        np.testing.assert_array_equal(g0, o0)
+        np.testing.assert_array_equal(g1, o1)
+        assert gi[123] == 70 and len(o0) > 1000
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "vsm_upload_u8_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "vsm_upload_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vsm_upload_f32_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "vsm_set_scratch_budget": (C.c_int, [C.c_void_p, C.c_longlong]),
     "vsm_set_f32_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "vsm_last_f32_path": (C.c_int, [C.c_void_p]),
     "vsm_release_set": (C.c_int, [C.c_void_p, C.c_int]),
@@ -267,6 +268,10 @@ class Matcher:
         return (res.reshape(x.shape) if want_result else None), argmin.reshape((b,) + tuple(x.shape[2:]))
 
     # ---- measurement --------------------------------------------------------------------
+    def set_scratch_budget(self, nbytes):
+        """Device scratch one submission of match_pairs may use (the pair list is cut accordingly)."""
+        self._check(self._l.vsm_set_scratch_budget(self._h, int(nbytes)))
+
     def set_f32_mode(self, mode):
         """0 = bf16 coarse pass + exact re-rank (default), 1 = f32 matrix cores only; same results."""
         self._check(self._l.vsm_set_f32_mode(self._h, int(mode)))

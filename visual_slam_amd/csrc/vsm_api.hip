@@ -23,6 +23,8 @@ struct DevBuf {
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
+        // hipFree waits for the device to go idle, so growing a buffer that a queued submission
+        // still uses is safe (it costs a stall, and only while the workspace is still growing)
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
@@ -99,6 +101,7 @@ struct vsm_ctx {
         hipEvent_t packed = nullptr;
     } slots[2];
     int rs = 0;   // slot the next submission uses / the last one used
+    size_t scratch_budget = (size_t)8 << 30;   // device scratch one submission may use
     ResultSlot& R() { return slots[rs]; }
     hipStream_t copy_stream = nullptr;
     // last device-resident result
@@ -158,7 +161,7 @@ int check_params(vsm_ctx* c, const vsm_params* p)
 
 // One submission may use this many bytes of per-row scratch (partial results, candidate and
 // output lists: about 40 bytes per image-0 row).
-constexpr size_t kScratchBudget = (size_t)8 << 30;
+constexpr size_t kDefaultScratchBudget = (size_t)8 << 30;
 constexpr size_t kScratchPerRow = 40;
 
 struct Plan {
@@ -198,9 +201,9 @@ int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
         if (!empty)
             for (int vb = 0; vb * kVerifyBlock < A->n; ++vb) pl.vitems.push_back(SiftItem{p, (int16_t)vb, 0});
     }
-    if ((pl.rows + pl.out0) * kScratchPerRow > kScratchBudget)
+    if ((pl.rows + pl.out0) * kScratchPerRow > std::max(c->scratch_budget, kDefaultScratchBudget))
         return fail(c, VSM_EINVAL, "submission needs about %zu bytes of scratch (limit %zu); submit fewer pairs per call",
-                    (pl.rows + pl.out0) * kScratchPerRow, kScratchBudget);
+                    (pl.rows + pl.out0) * kScratchPerRow, std::max(c->scratch_budget, kDefaultScratchBudget));
     return VSM_OK;
 }
 
@@ -1008,7 +1011,7 @@ extern "C" long long vsm_match_pairs(vsm_ctx* c, const int32_t* pairs, int npair
             const size_t need = A->kind == SET_F32
                                     ? ((size_t)A->n_pad + B->n_pad) * 2 * (kCoarseCap * 8 + 16 + 64)
                                     : (chunks * A->n_pad + A->n) * kScratchPerRow;
-            if (take > 0 && (scratch + need > kScratchBudget / 2 || take >= 8192)) break;
+            if (take > 0 && (scratch + need > c->scratch_budget / 2 || take >= 8192)) break;
             scratch += need;
             ++take;
         }
@@ -1249,6 +1252,14 @@ extern "C" int vsm_knn2(vsm_ctx* c, int set_q, int set_db, int metric,
     if (d2) HIPCHK(c, hipMemcpyAsync(d2, c->d_knn2.p, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return A->n;
+}
+
+extern "C" int vsm_set_scratch_budget(vsm_ctx* c, long long bytes)
+{
+    if (!c) return VSM_EINVAL;
+    if (bytes < (1ll << 20)) return fail(c, VSM_EINVAL, "scratch budget %lld is below 1 MiB", bytes);
+    c->scratch_budget = (size_t)bytes;
+    return VSM_OK;
 }
 
 extern "C" int vsm_set_f32_mode(vsm_ctx* c, int mode)
