@@ -186,6 +186,15 @@ long long vsm_image_pairs_exhaustive(int nimages, int32_t* pairs, long long cap)
  * reference default of 20. */
 int vsm_mat_write_pmatch(const char* image1, const char* image2, int fc1, int fc2,
                          int nm, const int32_t* idx1, const int32_t* idx2, int reservation);
+/* The same writer for long runs (SfM over thousands of pairs): every touched file's directory is
+ * read once and kept in memory, at most max_open (<= 0: 256) descriptors stay open, directories are
+ * written back by vsm_mat_writer_close.  The files end up byte for byte as repeated
+ * vsm_mat_write_pmatch calls leave them; until close they are incomplete. */
+typedef struct vsm_matwriter vsm_matwriter;
+vsm_matwriter* vsm_mat_writer_open(int reservation, int max_open);
+int vsm_mat_writer_put(vsm_matwriter* w, const char* image1, const char* image2, int fc1, int fc2,
+                       int nm, const int32_t* idx1, const int32_t* idx2);
+int vsm_mat_writer_close(vsm_matwriter* w);
 /* MatchFile(image).GetPMatch(other, FC, NM, matches) (MatchFile.cpp:856-895). */
 int vsm_mat_get_pmatch(const char* image, const char* other, int fc_other,
                        int32_t* idx_this, int32_t* idx_other, int cap);

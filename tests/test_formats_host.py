@@ -214,3 +214,36 @@ def test_ratio_fraction():
     assert B.ratio_to_fraction(None) == (0, 1)
     n, d = B.ratio_to_fraction(0.7)
     assert (n, d) == (7, 10)
+
+
+def test_mat_writer_leaves_the_same_bytes_as_repeated_calls(tmp_path):
+    """Cached writer (few descriptors open, directories in memory) against one call per pair, with a
+    small reservation (directory regrow) and pairs written twice with more matches (block moves)."""
+    rng = np.random.default_rng(77)
+    n = 30
+    fc = [int(x) for x in rng.integers(50, 400, n)]
+    pairs = [(a, b) for a in range(n) for b in range(a + 1, n)]
+    puts = []
+    for a, b in pairs:
+        nm = int(rng.integers(0, min(fc[a], fc[b])))
+        puts.append((a, b, np.sort(rng.choice(fc[a], nm, replace=False)).astype(np.int32),
+                     rng.choice(fc[b], nm, replace=False).astype(np.int32)))
+    for a, b in pairs[::7]:     # the same pair again, with more matches than its block holds
+        nm = min(fc[a], fc[b])
+        puts.append((a, b, np.arange(nm, dtype=np.int32), rng.permutation(fc[b])[:nm].astype(np.int32)))
+    d1, d2 = tmp_path / "calls", tmp_path / "writer"
+    d1.mkdir()
+    d2.mkdir()
+    for a, b, i0, i1 in puts:
+        host.write_pmatch(str(d1 / ("im%d" % a)), str(d1 / ("im%d" % b)), fc[a], fc[b], i0, i1, reservation=4)
+    with host.MatWriter(reservation=4, max_open=5) as w:
+        for a, b, i0, i1 in puts:
+            w.put(str(d2 / ("im%d" % a)), str(d2 / ("im%d" % b)), fc[a], fc[b], i0, i1)
+    for a in range(n):
+        x = (d1 / ("im%d.mat" % a)).read_bytes()
+        y = (d2 / ("im%d.mat" % a)).read_bytes()
+        assert x == y, "im%d.mat differs" % a
+    a, b, i0, i1 = puts[-1]
+    ga, gb = host.get_pmatch(str(d2 / ("im%d" % a)), str(d2 / ("im%d" % b)), fc[b])
+    np.testing.assert_array_equal(ga, i0)
+    np.testing.assert_array_equal(gb, i1)

@@ -85,6 +85,9 @@ SIGNATURES = {
     "vsm_image_pairs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "vsm_image_pairs_exhaustive": (C.c_longlong, [C.c_int, C.c_void_p, C.c_longlong]),
     "vsm_mat_write_pmatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "vsm_mat_writer_open": (C.c_void_p, [C.c_int, C.c_int]),
+    "vsm_mat_writer_put": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vsm_mat_writer_close": (C.c_int, [C.c_void_p]),
     "vsm_mat_get_pmatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "vsm_mat_get_pmatch_r": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "vsm_mat_get_match_count": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

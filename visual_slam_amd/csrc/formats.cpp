@@ -17,7 +17,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <list>
+#include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -464,16 +467,30 @@ public:
             hdr_ = MatHeader{kMatVersion, 0, 0, 0, 0};  // MatchFile.cpp:563-573
             dir_.clear();
             recs_.clear();
+            by_name_.clear();
         }
         return true;
     }
-    ~MatFile() { if (fd_ >= 0) ::close(fd_); }
+    ~MatFile() { close_fd(); }
+    // The directory stays in memory; the descriptor can be dropped and taken again (long runs over
+    // more files than a process may hold open).
+    void close_fd()
+    {
+        if (fd_ >= 0) ::close(fd_);
+        fd_ = -1;
+    }
+    bool ensure_fd()
+    {
+        if (fd_ >= 0) return true;
+        fd_ = ::open((image_ + ".mat").c_str(), O_CREAT | O_RDWR, S_IRUSR | S_IWUSR);
+        return fd_ >= 0;
+    }
 
+    // first record with this name (the reference searches linearly, MatchFile.cpp:347-369)
     int find(const std::string& rel) const
     {
-        for (size_t i = 0; i < recs_.size(); ++i)
-            if (rel == rec(i)->file_name) return (int)i;
-        return -1;
+        auto it = by_name_.find(rel);
+        return it == by_name_.end() ? -1 : it->second;
     }
     const MatRecLoc* rec(size_t i) const { return reinterpret_cast<const MatRecLoc*>(dir_.data() + recs_[i]); }
     MatRecLoc* rec(size_t i) { return reinterpret_cast<MatRecLoc*>(dir_.data() + recs_[i]); }
@@ -492,6 +509,7 @@ public:
             dir_.assign((size_t)hdr_.definition_buf, 0);
             hdr_.definition_size = 0;
             recs_.clear();
+            by_name_.clear();
             append_record(rel, elen, rlen, (int32_t)sizeof(MatHeader) + hdr_.definition_buf);
             return 0;
         }
@@ -563,6 +581,8 @@ private:
             recs_.push_back(p);
             p += sizeof(MatRecLoc) + (size_t)r->extra_size;
         }
+        by_name_.clear();
+        for (size_t i = 0; i < recs_.size(); ++i) by_name_.emplace(rec(i)->file_name, (int)i);   // keeps the first
         if ((int)recs_.size() != hdr_.file_count) {
             hdr_.file_count = (int)recs_.size();
             hdr_.definition_size = (int32_t)p;
@@ -577,6 +597,7 @@ private:
         r->extra_size = elen;
         memcpy(r->file_name, rel.c_str(), rel.size() + 1);
         recs_.push_back(at);
+        by_name_.emplace(rel, (int)recs_.size() - 1);
         hdr_.definition_size += rlen;
         hdr_.file_count = (int)recs_.size();
     }
@@ -622,13 +643,14 @@ private:
     MatHeader hdr_{};
     std::vector<char> dir_;
     std::vector<size_t> recs_;  // byte offsets of the records inside dir_
+    std::unordered_map<std::string, int> by_name_;
 };
 
-int mat_write_one(const std::string& image, const std::string& other, int fc_other, int nm,
-                  const int32_t* row_this, const int32_t* row_other, int reservation)
+// One record into an open file.  flush_dir = false leaves the changed directory in memory only.
+int mat_put(MatFile& mf, const std::string& other, int fc_other, int nm, const int32_t* row_this,
+            const int32_t* row_other, int reservation, bool flush_dir)
 {
-    MatFile mf;
-    if (!mf.open(image, true)) return VSM_EIO;
+    const std::string& image = mf.image();
     const std::string rel = relative_name(image, other);
     if ((int)rel.size() >= kMaxPath) return VSM_EINVAL;
     int idx = mf.find(rel);
@@ -657,7 +679,7 @@ int mat_write_one(const std::string& image, const std::string& other, int fc_oth
         }
     }
     loc->fcount = fc_other;
-    if (!mf.flush_directory()) return VSM_EIO;
+    if (flush_dir && !mf.flush_directory()) return VSM_EIO;
     // MatchFile.cpp:813-831
     MatRecord rec;
     memset(&rec, 0, sizeof rec);
@@ -674,7 +696,88 @@ int mat_write_one(const std::string& image, const std::string& other, int fc_oth
     return mf.write_at(loc->read_loc, blk.data(), blk.size()) ? VSM_OK : VSM_EIO;
 }
 
+int mat_write_one(const std::string& image, const std::string& other, int fc_other, int nm,
+                  const int32_t* row_this, const int32_t* row_other, int reservation)
+{
+    MatFile mf;
+    if (!mf.open(image, true)) return VSM_EIO;
+    return mat_put(mf, other, fc_other, nm, row_this, row_other, reservation, true);
+}
+
 }  // namespace
+
+// Writer for long runs (the reference re-opens both files, re-reads and re-writes their directories
+// and searches the partner name linearly on every WritePMatch call, MatchFile.cpp:347-369, 751-832):
+// every touched file's directory is parsed once and kept in memory, written back when the writer is
+// closed; at most `max_open` descriptors stay open.  The files end up byte for byte as repeated
+// vsm_mat_write_pmatch calls leave them.
+struct vsm_matwriter {
+    int reservation = 0;
+    size_t max_open = 256;
+    std::unordered_map<std::string, std::unique_ptr<MatFile>> files;
+    std::list<MatFile*> open_order;   // least recently used first
+    bool failed = false;
+
+    MatFile* get(const std::string& image)
+    {
+        auto it = files.find(image);
+        MatFile* mf;
+        if (it == files.end()) {
+            std::unique_ptr<MatFile> fresh(new MatFile());
+            if (!fresh->open(image, true)) return nullptr;
+            mf = fresh.get();
+            files.emplace(image, std::move(fresh));
+        } else {
+            mf = it->second.get();
+            open_order.remove(mf);
+            if (!mf->ensure_fd()) return nullptr;
+        }
+        open_order.push_back(mf);
+        while (open_order.size() > max_open) {
+            open_order.front()->close_fd();
+            open_order.pop_front();
+        }
+        return mf;
+    }
+};
+
+extern "C" vsm_matwriter* vsm_mat_writer_open(int reservation, int max_open)
+{
+    vsm_matwriter* w = new vsm_matwriter();
+    w->reservation = reservation;
+    if (max_open > 0) w->max_open = (size_t)max_open;
+    return w;
+}
+
+extern "C" int vsm_mat_writer_put(vsm_matwriter* w, const char* image1, const char* image2, int fc1, int fc2,
+                                  int nm, const int32_t* idx1, const int32_t* idx2)
+{
+    if (!w || !image1 || !image2 || !image1[0] || !image2[0] || nm < 0 || (nm > 0 && (!idx1 || !idx2))) return VSM_EINVAL;
+    if (strlen(image1) + 5 > (size_t)kMaxPath || strlen(image2) + 5 > (size_t)kMaxPath) return VSM_EINVAL;
+    if (w->failed) return VSM_EIO;
+    MatFile* a = w->get(image1);
+    int rc = a ? mat_put(*a, image2, fc2, nm, idx1, idx2, w->reservation, false) : VSM_EIO;
+    if (rc == VSM_OK) {
+        MatFile* b = w->get(image2);
+        rc = b ? mat_put(*b, image1, fc1, nm, idx2, idx1, w->reservation, false) : VSM_EIO;
+    }
+    if (rc == VSM_EIO) w->failed = true;
+    return rc;
+}
+
+extern "C" int vsm_mat_writer_close(vsm_matwriter* w)
+{
+    if (!w) return VSM_EINVAL;
+    bool ok = !w->failed;
+    for (auto& kv : w->files) {
+        MatFile* mf = kv.second.get();
+        if (mf->count() == 0) continue;
+        if (!mf->ensure_fd() || !mf->flush_directory()) ok = false;
+        mf->close_fd();
+    }
+    delete w;
+    return ok ? VSM_OK : VSM_EIO;
+}
 
 extern "C" int vsm_mat_write_pmatch(const char* image1, const char* image2, int fc1, int fc2,
                                     int nm, const int32_t* idx1, const int32_t* idx2, int reservation)

@@ -206,6 +206,7 @@ int main(int argc, char** argv)
     bool finished = false, write_failed = false;
     std::string write_error;
 
+    vsm_matwriter* mw = o.write_mat ? vsm_mat_writer_open(o.num, 0) : nullptr;
     std::thread writer([&]() {
         for (int cur = 0;; cur ^= 1) {
             {
@@ -225,8 +226,8 @@ int main(int argc, char** argv)
                 }
                 if (o.write_mat && !write_failed) {
                     const std::string p0 = o.sift_dir + "/" + std::to_string(ia), p1 = o.sift_dir + "/" + std::to_string(ib);
-                    const int rc = vsm_mat_write_pmatch(p0.c_str(), p1.c_str(), count[ia], count[ib], nm,
-                                                        b.idx0.data() + b.off[k], b.idx1.data() + b.off[k], o.num);
+                    const int rc = vsm_mat_writer_put(mw, p0.c_str(), p1.c_str(), count[ia], count[ib], nm,
+                                                      b.idx0.data() + b.off[k], b.idx1.data() + b.off[k]);
                     if (rc < 0) {
                         write_failed = true;
                         write_error = "cannot write .mat for pair " + std::to_string(ia) + " " + std::to_string(ib);
@@ -290,6 +291,10 @@ int main(int argc, char** argv)
     if (gpu_failed) return 1;
     if (write_failed) {
         fprintf(stderr, "%s\n", write_error.c_str());
+        return 1;
+    }
+    if (mw && vsm_mat_writer_close(mw) != VSM_OK) {
+        fprintf(stderr, "error writing .mat files\n");
         return 1;
     }
     if (vsm_matchtxt_close(tw) != VSM_OK) {

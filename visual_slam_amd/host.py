@@ -125,6 +125,33 @@ def write_pmatch(image1, image2, fc1, fc2, idx1, idx2, reservation=0):
         raise B.VsmError(rc, "vsm_mat_write_pmatch(%s, %s)" % (image1, image2))
 
 
+class MatWriter:
+    """Many write_pmatch calls with every file's directory kept in memory (written back on close)."""
+
+    def __init__(self, reservation=0, max_open=0):
+        self._w = B.lib().vsm_mat_writer_open(int(reservation), int(max_open))
+
+    def put(self, image1, image2, fc1, fc2, idx1, idx2):
+        i1 = np.ascontiguousarray(idx1, dtype=np.int32)
+        i2 = np.ascontiguousarray(idx2, dtype=np.int32)
+        rc = B.lib().vsm_mat_writer_put(self._w, _b(image1), _b(image2), int(fc1), int(fc2), len(i1), B._ptr(i1), B._ptr(i2))
+        if rc < 0:
+            raise B.VsmError(rc, "vsm_mat_writer_put(%s, %s)" % (image1, image2))
+
+    def close(self):
+        if self._w:
+            rc = B.lib().vsm_mat_writer_close(self._w)
+            self._w = None
+            if rc < 0:
+                raise B.VsmError(rc, "vsm_mat_writer_close")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def get_pmatch(image, other, fc_other):
     nm = B.lib().vsm_mat_get_pmatch(_b(image), _b(other), int(fc_other), None, None, 0)
     a = np.empty(max(nm, 1), np.int32)
