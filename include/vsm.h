@@ -110,6 +110,13 @@ int vsm_match_pair_dense(vsm_ctx* ctx, int set0, int set1, const vsm_params* p, 
 long long vsm_match_pairs(vsm_ctx* ctx, const int32_t* pairs, int npairs, const vsm_params* p,
                           int metric, int64_t* offsets, int32_t* idx0, int32_t* idx1,
                           long long cap);
+/* The two halves of vsm_match_pairs for callers that keep the GPU fed across calls: submit queues one
+ * submission (it must fit the scratch budget) and returns at once; collect waits for the OLDEST
+ * submission in flight and copies its lists (offsets[npairs+1] relative to that submission).  At most
+ * two submissions are in flight; the pattern is submit(0), submit(1), collect(0), submit(2), ...
+ * Float pairs are searched inside submit and cannot be queued behind another submission. */
+int vsm_submit_pairs(vsm_ctx* ctx, const int32_t* pairs, int npairs, const vsm_params* p, int metric);
+long long vsm_collect_matches(vsm_ctx* ctx, int64_t* offsets, int32_t* idx0, int32_t* idx1, long long cap);
 /* Device scratch vsm_match_pairs may use per submission (default 8 GiB, at least 1 MiB): it cuts
  * the pair list into submissions of about half that and keeps two of them in flight (the next one is
  * queued before the lists of the last one are fetched).  A single pair is never cut. */
@@ -145,6 +152,8 @@ int vsm_nearest_embed(vsm_ctx* ctx, const float* x, int batch, int dim, int npts
  * the context's stream; vsm_last_kernel_ms returns the last bracket (synchronises). */
 int vsm_set_timing(vsm_ctx* ctx, int on);
 float vsm_last_kernel_ms(vsm_ctx* ctx);
+/* Pairs in the submission that bracket belongs to (vsm_match_pairs may cut its list into several). */
+int vsm_last_submission_pairs(const vsm_ctx* ctx);
 /* Same for the mutual-check pass of a u8 submission (-1 when it did not run). */
 float vsm_last_verify_ms(vsm_ctx* ctx);
 

@@ -190,3 +190,33 @@ def test_stress_pair_65536(matcher):
     finally:
         matcher.release(s0)
         matcher.release(s1)
+
+
+def test_submit_collect_keeps_order(matcher):
+    """Two submissions in flight: lists come back oldest first; a third submit and an idle collect fail."""
+    import visual_slam_amd as vsm
+    rng = np.random.default_rng(16)
+    imgs = [synth.sift_pair(700, 900, seed=100 + k) for k in range(3)]
+    ids = [(matcher.upload_u8(a), matcher.upload_u8(b)) for a, b in imgs]
+    batches = [[ids[0], ids[1]], [ids[2]], [ids[1], ids[0], ids[2]]]
+    matcher.submit_pairs(batches[0])
+    matcher.submit_pairs(batches[1])
+    with pytest.raises(vsm.VsmError):
+        matcher.submit_pairs(batches[2])
+    got = [matcher.collect_matches()]
+    matcher.submit_pairs(batches[2])
+    got.append(matcher.collect_matches())
+    got.append(matcher.collect_matches())
+    with pytest.raises(vsm.VsmError):
+        matcher._inflight.append((1, 1))
+        matcher.collect_matches()
+    order = [[0, 1], [2], [1, 0, 2]]
+    for (off, i0, i1), which in zip(got, order):
+        assert len(off) == len(which) + 1
+        for k, w in enumerate(which):
+            o0, o1, _ = orc.match_u8(imgs[w][0], imgs[w][1], orc.params((4, 5), True))
+            np.testing.assert_array_equal(i0[off[k]:off[k + 1]], o0)
+            np.testing.assert_array_equal(i1[off[k]:off[k + 1]], o1)
+    for a, b in ids:
+        matcher.release(a)
+        matcher.release(b)

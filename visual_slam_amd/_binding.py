@@ -63,6 +63,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "vsm_match_pairs": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Params), C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]),
+    "vsm_submit_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Params), C.c_int]),
+    "vsm_collect_matches": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]),
     "vsm_match_pairs_device": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Params), C.c_int]),
     "vsm_fetch_matches": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]),
     "vsm_knn2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -73,6 +75,7 @@ SIGNATURES = {
     "vsm_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "vsm_last_kernel_ms": (C.c_float, [C.c_void_p]),
     "vsm_last_verify_ms": (C.c_float, [C.c_void_p]),
+    "vsm_last_submission_pairs": (C.c_int, [C.c_void_p]),
     "vsm_sift_read": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vsm_sift_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "vsm_feature_txt_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int]),
@@ -138,6 +141,7 @@ class Matcher:
         if not self._h:
             raise VsmError(-2, self._l.vsm_last_error(None).decode())
         self._kinds = {}
+        self._inflight = []
 
     def close(self):
         if getattr(self, "_h", None):
@@ -234,6 +238,23 @@ class Matcher:
                                                   _ptr(off), _ptr(idx0), _ptr(idx1), cap))
         return off, idx0[:tot].copy(), idx1[:tot].copy()
 
+    def submit_pairs(self, pairs, ratio=0.8, mutual=True, max_dist_sq=-1, metric=METRIC_L2,
+                     min_score=float("-inf"), max_dist_sq_f=-1.0):
+        """Queues one submission (at most two in flight); collect_matches returns the oldest one's lists."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        p = make_params(ratio, mutual, max_dist_sq, min_score, max_dist_sq_f)
+        self._check(self._l.vsm_submit_pairs(self._h, _ptr(pairs), len(pairs), C.byref(p), metric))
+        self._inflight.append((len(pairs), int(sum(self._kinds[int(a)][1] for a in pairs[:, 0])) or 1))
+
+    def collect_matches(self, bufs=None):
+        """bufs: optional (offsets, idx0, idx1) numpy arrays to reuse (large enough for the submission)."""
+        npairs, cap = self._inflight.pop(0)
+        if bufs is None:
+            bufs = (np.empty(npairs + 1, np.int64), np.empty(cap, np.int32), np.empty(cap, np.int32))
+        off, idx0, idx1 = bufs
+        tot = self._check(self._l.vsm_collect_matches(self._h, _ptr(off), _ptr(idx0), _ptr(idx1), min(cap, len(idx0))))
+        return off[:npairs + 1], idx0[:tot], idx1[:tot]
+
     def match_pairs_device(self, pairs, ratio=0.8, mutual=True, max_dist_sq=-1, metric=METRIC_L2,
                            min_score=float("-inf"), max_dist_sq_f=-1.0):
         pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
@@ -287,6 +308,9 @@ class Matcher:
 
     def last_kernel_ms(self):
         return float(self._l.vsm_last_kernel_ms(self._h))
+
+    def last_submission_pairs(self):
+        return int(self._l.vsm_last_submission_pairs(self._h))
 
     def last_verify_ms(self):
         return float(self._l.vsm_last_verify_ms(self._h))

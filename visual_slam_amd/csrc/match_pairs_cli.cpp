@@ -22,7 +22,7 @@ namespace {
 
 struct Options {
     std::string sift_dir, out = "matching.txt", name_ext = ".jpg", sift_ext = ".sift";
-    int num = 0, device = 0, batch = 8192;
+    int num = 0, device = 0, batch = 4096;
     int shard = 0, nshards = 1;
     bool exhaustive = true, mutual = true, write_mat = false, append = false;
     int consecutive = 3;
@@ -45,7 +45,7 @@ void usage()
             "  --no-mutual           skip the mutual-nearest-neighbour check\n"
             "  --mat                 also write <DIR>/<i>.mat putative-match records\n"
             "  --name-ext EXT        image-name suffix in the match txt (default .jpg)\n"
-            "  --device N, --batch P (pairs per library call, default 8192)\n"
+            "  --device N, --batch P (pairs per GPU submission, default 4096; two are in flight)\n"
             "  --shard R/W           match only the R-th of W contiguous slices of the pair list (one process\n"
             "                        per GPU); with W > 1 the text goes to FILE.partR: concatenating the parts in\n"
             "                        order gives the file of an unsharded run\n");
@@ -242,35 +242,51 @@ int main(int argc, char** argv)
         }
     });
 
+    // GPU side: submission k + 1 is queued before the lists of submission k are collected, so the
+    // device never waits for this thread or for the writer
     std::vector<int32_t> ids;
     long long total = 0;
     bool gpu_failed = false;
-    int cur = 0;
-    for (long long lo = 0; lo < npairs && !gpu_failed; lo += o.batch, cur ^= 1) {
+    const long long nbatches = (npairs + o.batch - 1) / o.batch;
+    auto submit = [&](long long k) {
+        const long long lo = k * o.batch;
+        const int take = (int)std::min<long long>(o.batch, npairs - lo);
+        ids.resize((size_t)take * 2);
+        for (int q = 0; q < take; ++q) {
+            ids[2 * q] = set_id[pairs[2 * (lo + q)]];
+            ids[2 * q + 1] = set_id[pairs[2 * (lo + q) + 1]];
+        }
+        if (vsm_submit_pairs(ctx, ids.data(), take, &prm, VSM_METRIC_L2) != VSM_OK) {
+            fprintf(stderr, "vsm_submit_pairs: %s\n", vsm_last_error(ctx));
+            return false;
+        }
+        return true;
+    };
+    if (nbatches > 0 && !submit(0)) gpu_failed = true;
+    for (long long k = 0; k < nbatches && !gpu_failed; ++k) {
+        if (k + 1 < nbatches && !submit(k + 1)) {
+            gpu_failed = true;
+            break;
+        }
+        const int cur = (int)(k & 1);
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return filled[cur] == 0; });
         }
         if (write_failed) break;
         Batch& b = batches[cur];
+        const long long lo = k * o.batch;
         const int take = (int)std::min<long long>(o.batch, npairs - lo);
-        ids.resize((size_t)take * 2);
         size_t cap = 1;
-        for (int k = 0; k < take; ++k) {
-            const int ia = pairs[2 * (lo + k)], ib = pairs[2 * (lo + k) + 1];
-            ids[2 * k] = set_id[ia];
-            ids[2 * k + 1] = set_id[ib];
-            cap += (size_t)count[ia];
-        }
+        for (int q = 0; q < take; ++q) cap += (size_t)count[pairs[2 * (lo + q)]];
         b.lo = lo;
         b.take = take;
         b.idx0.resize(cap);
         b.idx1.resize(cap);
         b.off.resize((size_t)take + 1);
-        const long long got = vsm_match_pairs(ctx, ids.data(), take, &prm, VSM_METRIC_L2, b.off.data(),
-                                              b.idx0.data(), b.idx1.data(), (long long)cap);
+        const long long got = vsm_collect_matches(ctx, b.off.data(), b.idx0.data(), b.idx1.data(), (long long)cap);
         if (got < 0) {
-            fprintf(stderr, "vsm_match_pairs: %s\n", vsm_last_error(ctx));
+            fprintf(stderr, "vsm_collect_matches: %s\n", vsm_last_error(ctx));
             gpu_failed = true;
             break;
         }

@@ -133,21 +133,6 @@ __device__ __forceinline__ void stage_step(char* smem, int buf, const int8_t* fr
     if (wave < 4) dma4(nrm_src, smem + 2 * kLdsTile + buf * kLdsNorm + wave * 256);
 }
 
-// per-tile accumulators of one wave: streamed tile (A operand) x persistent rows (B operand)
-__device__ __forceinline__ v16i tile_dot(const char* tile_lds, const v4i (&pf)[4])
-{
-    const v4i b0 = *reinterpret_cast<const v4i*>(tile_lds);
-    const v4i b1 = *reinterpret_cast<const v4i*>(tile_lds + 1024);
-    const v4i b2 = *reinterpret_cast<const v4i*>(tile_lds + 2048);
-    const v4i b3 = *reinterpret_cast<const v4i*>(tile_lds + 3072);
-    v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b0, pf[0], z, 0, 0, 0);
-    z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b1, pf[1], z, 0, 0, 0);
-    z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b2, pf[2], z, 0, 0, 0);
-    z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b3, pf[3], z, 0, 0, 0);
-    return z;
-}
-
 // the 16 packed norms of the streamed rows this lane's registers hold (4 x 16-byte LDS reads)
 __device__ __forceinline__ void tile_consts(const int* nl_tile, int half, int (&c)[16])
 {
@@ -310,8 +295,12 @@ void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
 
 // ---- 3. verify pass -------------------------------------------------------------------
 // Persistent rows = the image-1 rows named by a block of 256 candidates (gathered from the
-// operand-order layout); streamed set = all of image 0.  Per candidate: the nearest image-0 row.
-__global__ __launch_bounds__(512, 2)
+// operand-order layout: kVerifyRB blocks of 32 per wave, sharing every streamed operand read);
+// streamed set = all of image 0.  Per candidate: the nearest image-0 row.
+constexpr int kVerifyWaves = 4;
+constexpr int kVerifyRB = kVerifyBlock / (32 * kVerifyWaves);
+
+__global__ __launch_bounds__(kVerifyWaves * 64, 2)
 void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ vitems,
                         SiftCandidates cand, int negscale)
 {
@@ -328,65 +317,86 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
     const int lane5 = lane & 31;
     const int half = lane >> 5;
 
-    const int ci = cbase + wave * 32 + lane5;
-    const bool valid = ci < ncand;
-    const int j = valid ? cand.j1[pw.out0_off + ci] : 0;
-    v4i pf[4];
-    {
+    int ci[kVerifyRB];
+    v4i pf[kVerifyRB][4];
+#pragma unroll
+    for (int rb = 0; rb < kVerifyRB; ++rb) {
+        ci[rb] = cbase + (wave * kVerifyRB + rb) * 32 + lane5;
+        const int j = ci[rb] < ncand ? cand.j1[pw.out0_off + ci[rb]] : 0;
         const int8_t* src = pw.fragB + (size_t)(j >> 5) * kTileBytes + (half * 32 + (j & 31)) * 16;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) pf[s] = *reinterpret_cast<const v4i*>(src + s * 1024);
+        for (int s = 0; s < 4; ++s) pf[rb][s] = *reinterpret_cast<const v4i*>(src + s * 1024);
     }
 
     const int nsteps = pw.nA_pad / kStepRows;
-    const int8_t* Asrc = pw.fragA + wave * 4096 + lane * 16;
+    const int8_t* Asrc = pw.fragA + wave * (kLdsTile / kVerifyWaves) + lane * 16;
     const int32_t* Nsrc = pw.nrmA + (wave & 3) * 64 + lane;
 
-    int bestd = kDistPad, bestrow = INT32_MAX;
+    int bestd[kVerifyRB], bestrow[kVerifyRB];
+#pragma unroll
+    for (int rb = 0; rb < kVerifyRB; ++rb) { bestd[rb] = kDistPad; bestrow[rb] = INT32_MAX; }
 
-    stage_step<8>(smem, 0, Asrc, Nsrc, wave);
+    stage_step<kVerifyWaves>(smem, 0, Asrc, Nsrc, wave);
     __syncthreads();
 
     for (int st = 0; st < nsteps; ++st) {
         const int cur = st & 1;
         if (st + 1 < nsteps)
-            stage_step<8>(smem, cur ^ 1, Asrc + (size_t)(st + 1) * kLdsTile, Nsrc + (st + 1) * kStepRows, wave);
+            stage_step<kVerifyWaves>(smem, cur ^ 1, Asrc + (size_t)(st + 1) * kLdsTile, Nsrc + (st + 1) * kStepRows, wave);
         const char* At = smem + cur * kLdsTile + lane * 16;
         const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm);
-        int m = INT32_MAX;
-        v16i acc = tile_dot(At, pf);
+        int m[kVerifyRB];
+#pragma unroll
+        for (int rb = 0; rb < kVerifyRB; ++rb) m[rb] = INT32_MAX;
 #pragma unroll
         for (int t = 0; t < kTilesPerStep; ++t) {
-            v16i nxt = acc;
-            if (t + 1 < kTilesPerStep) nxt = tile_dot(At + (t + 1) * 4096, pf);
+            const char* tile = At + t * 4096;
+            const v4i b0 = *reinterpret_cast<const v4i*>(tile);
+            const v4i b1 = *reinterpret_cast<const v4i*>(tile + 1024);
+            const v4i b2 = *reinterpret_cast<const v4i*>(tile + 2048);
+            const v4i b3 = *reinterpret_cast<const v4i*>(tile + 3072);
             int c[16];
             tile_consts(nl + t * 32, half, c);
+            v16i acc[kVerifyRB];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int y0 = __mul24(acc[2 * e], negscale) + c[2 * e];
-                const int y1 = __mul24(acc[2 * e + 1], negscale) + c[2 * e + 1];
-                m = min3i(m, y0, y1);
+            for (int rb = 0; rb < kVerifyRB; ++rb) {
+                v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b0, pf[rb][0], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b1, pf[rb][1], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b2, pf[rb][2], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b3, pf[rb][3], z, 0, 0, 0);
+                acc[rb] = z;
             }
-            acc = nxt;
+#pragma unroll
+            for (int rb = 0; rb < kVerifyRB; ++rb) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int y0 = __mul24(acc[rb][2 * e], negscale) + c[2 * e];
+                    const int y1 = __mul24(acc[rb][2 * e + 1], negscale) + c[2 * e + 1];
+                    m[rb] = min3i(m[rb], y0, y1);
+                }
+            }
         }
-        {
-            const int d = m >> 8;
-            if (d < bestd) {
-                bestd = d;
-                bestrow = st * kStepRows + (m & 255);
+#pragma unroll
+        for (int rb = 0; rb < kVerifyRB; ++rb) {
+            const int d = m[rb] >> 8;
+            if (d < bestd[rb]) {
+                bestd[rb] = d;
+                bestrow[rb] = st * kStepRows + (m[rb] & 255);
             }
         }
         __syncthreads();
     }
-    {
-        const int od = __shfl_xor(bestd, 32);
-        const int orow = __shfl_xor(bestrow, 32);
-        if (od < bestd || (od == bestd && orow < bestrow)) {
-            bestd = od;
-            bestrow = orow;
+#pragma unroll
+    for (int rb = 0; rb < kVerifyRB; ++rb) {
+        const int od = __shfl_xor(bestd[rb], 32);
+        const int orow = __shfl_xor(bestrow[rb], 32);
+        if (od < bestd[rb] || (od == bestd[rb] && orow < bestrow[rb])) {
+            bestd[rb] = od;
+            bestrow[rb] = orow;
         }
+        if (half == 0 && ci[rb] < ncand) cand.vrow[pw.out0_off + ci[rb]] = bestrow[rb];
     }
-    if (half == 0 && valid) cand.vrow[pw.out0_off + ci] = bestrow;
 }
 
 void launch_sift_verify(const SiftPair* pairs, const SiftItem* vitems, int nvitems,
@@ -398,13 +408,10 @@ void launch_sift_verify(const SiftPair* pairs, const SiftItem* vitems, int nvite
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsStream);
         attr_set = true;
     }
-    hipLaunchKernelGGL(sift_verify_kernel, dim3(nvitems), dim3(512), kLdsStream, s,
+    hipLaunchKernelGGL(sift_verify_kernel, dim3(nvitems), dim3(kVerifyWaves * 64), kLdsStream, s,
                        pairs, vitems, cand, -512);
 }
 
-// ---------------------------------------------------------------------------------
-// block-wide compaction helper (1024 threads)
-// ---------------------------------------------------------------------------------
 // ---- 2. select ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024)
 void sift_select_kernel(const SiftPair* __restrict__ pairs,

@@ -99,8 +99,16 @@ struct vsm_ctx {
         DevBuf d_offsets, d_tight0, d_tight1;
         HostBuf h_pairs, h_items, h_off;
         hipEvent_t packed = nullptr;
+        // timing brackets of the submission that last used this slot
+        hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+        bool ev_valid = false, ev_verify_valid = false;
+        int query_pairs = 0;   // pairs in the launch the ev0..ev1 bracket belongs to
     } slots[2];
     int rs = 0;   // slot the next submission uses / the last one used
+    // submissions queued by vsm_submit_pairs and not yet collected (at most two, oldest first)
+    int inflight = 0, inflight_head = 0;
+    int inflight_pairs[2] = {0, 0};
+    bool inflight_on_host[2] = {false, false};   // float fall-back: lists already complete in the slot
     size_t scratch_budget = (size_t)8 << 30;   // device scratch one submission may use
     ResultSlot& R() { return slots[rs]; }
     hipStream_t copy_stream = nullptr;
@@ -109,8 +117,7 @@ struct vsm_ctx {
     long long last_total = 0;
     // timing
     int timing = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
-    bool ev_valid = false, ev_verify_valid = false;
+    int timing_slot = 0;   // slot whose brackets vsm_last_kernel_ms / vsm_last_verify_ms read
 };
 
 namespace {
@@ -216,6 +223,7 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
 {
     const int npairs = (int)pl.pairs.size();
     const int nitems = (int)pl.items.size();
+    c->R().query_pairs = npairs;
     const int nvitems = rule.mutual ? (int)pl.vitems.size() : 0;
     HIPCHK(c, c->R().h_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
     HIPCHK(c, c->R().h_items.ensure(sizeof(SiftItem) * std::max(nitems + nvitems, 1)));
@@ -254,15 +262,16 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     if (nitems + nvitems)
         HIPCHK(c, hipMemcpyAsync(c->d_items.p, c->R().h_items.p, sizeof(SiftItem) * (nitems + nvitems), hipMemcpyHostToDevice, c->stream));
 
-    c->ev_valid = false;
-    c->ev_verify_valid = false;
+    c->R().ev_valid = false;
+    c->timing_slot = c->rs;
+    c->R().ev_verify_valid = false;
     if (nitems) {
-        if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
         launch_sift_query(c->d_pairs.as<SiftPair>(), c->d_items.as<SiftItem>(), nitems,
                           c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), c->stream);
         if (c->timing) {
-            HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-            c->ev_valid = true;
+            HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
+            c->R().ev_valid = true;
         }
     }
     if (npairs) {
@@ -289,11 +298,11 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
         launch_sift_select(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(),
                            c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, out, c->stream);
         if (nvitems) {
-            if (c->timing) HIPCHK(c, hipEventRecord(c->ev2, c->stream));
+            if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev2, c->stream));
             launch_sift_verify(c->d_pairs.as<SiftPair>(), c->d_items.as<SiftItem>() + nitems, nvitems, cand, c->stream);
             if (c->timing) {
-                HIPCHK(c, hipEventRecord(c->ev3, c->stream));
-                c->ev_verify_valid = true;
+                HIPCHK(c, hipEventRecord(c->R().ev3, c->stream));
+                c->R().ev_verify_valid = true;
             }
         }
         launch_sift_confirm(c->d_pairs.as<SiftPair>(), npairs, cand, nvitems ? 1 : 0, out, c->stream);
@@ -360,8 +369,10 @@ extern "C" vsm_ctx* vsm_create(int device)
     vsm_ctx* c = new vsm_ctx();
     c->device = device;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev2)) != hipSuccess || (e = hipEventCreate(&c->ev3)) != hipSuccess ||
+        (e = hipEventCreate(&c->slots[0].ev0)) != hipSuccess || (e = hipEventCreate(&c->slots[0].ev1)) != hipSuccess ||
+        (e = hipEventCreate(&c->slots[0].ev2)) != hipSuccess || (e = hipEventCreate(&c->slots[0].ev3)) != hipSuccess ||
+        (e = hipEventCreate(&c->slots[1].ev0)) != hipSuccess || (e = hipEventCreate(&c->slots[1].ev1)) != hipSuccess ||
+        (e = hipEventCreate(&c->slots[1].ev2)) != hipSuccess || (e = hipEventCreate(&c->slots[1].ev3)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->slots[0].packed, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->slots[1].packed, hipEventDisableTiming)) != hipSuccess) {
@@ -401,10 +412,9 @@ extern "C" void vsm_destroy(vsm_ctx* c)
     c->h_small.release();
     c->h_probs.release();
     c->h_refs.release();
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->ev2) (void)hipEventDestroy(c->ev2);
-    if (c->ev3) (void)hipEventDestroy(c->ev3);
+    for (auto& r : c->slots)
+        for (hipEvent_t ev : {r.ev0, r.ev1, r.ev2, r.ev3})
+            if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -433,19 +443,19 @@ extern "C" int vsm_set_timing(vsm_ctx* c, int on)
 
 extern "C" float vsm_last_verify_ms(vsm_ctx* c)
 {
-    if (!c || !c->ev_verify_valid) return -1.0f;
-    if (hipEventSynchronize(c->ev3) != hipSuccess) return -1.0f;
+    if (!c || !c->slots[c->timing_slot].ev_verify_valid) return -1.0f;
+    if (hipEventSynchronize(c->slots[c->timing_slot].ev3) != hipSuccess) return -1.0f;
     float ms = -1.0f;
-    if (hipEventElapsedTime(&ms, c->ev2, c->ev3) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, c->slots[c->timing_slot].ev2, c->slots[c->timing_slot].ev3) != hipSuccess) return -1.0f;
     return ms;
 }
 
 extern "C" float vsm_last_kernel_ms(vsm_ctx* c)
 {
-    if (!c || !c->ev_valid) return -1.0f;
-    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0f;
+    if (!c || !c->slots[c->timing_slot].ev_valid) return -1.0f;
+    if (hipEventSynchronize(c->slots[c->timing_slot].ev1) != hipSuccess) return -1.0f;
     float ms = -1.0f;
-    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, c->slots[c->timing_slot].ev0, c->slots[c->timing_slot].ev1) != hipSuccess) return -1.0f;
     return ms;
 }
 
@@ -654,7 +664,8 @@ int coarse_overflowed(vsm_ctx* c, bool* overflow)
 int run_f32_knn(vsm_ctx* c, const DescSet* A, const DescSet* B, int metric, bool want_col, F32Result* r)
 {
     const size_t rows = (size_t)A->n_pad + B->n_pad;
-    c->ev_valid = false;
+    c->R().ev_valid = false;
+    c->timing_slot = c->rs;
     int rc;
     if (c->f32_mode == 0) {
         // bf16 coarse pass + exact re-rank; the train side of a mutual check is the same search
@@ -662,9 +673,9 @@ int run_f32_knn(vsm_ctx* c, const DescSet* A, const DescSet* B, int metric, bool
         std::vector<CoarseProblem> probs;
         probs.push_back(make_problem(A, B, metric));
         if (want_col) probs.push_back(make_problem(B, A, metric));
-        if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
         if ((rc = queue_coarse(c, probs, A->dim, rows)) != VSM_OK) return rc;
-        if (c->timing) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
         bool overflow = false;
         if ((rc = coarse_overflowed(c, &overflow)) != VSM_OK) return rc;
         if (!overflow) {
@@ -674,7 +685,7 @@ int run_f32_knn(vsm_ctx* c, const DescSet* A, const DescSet* B, int metric, bool
             r->k2 = c->d_knn2.as<float>();
             r->cidx = r->j1 + A->n_pad;
             r->ck = r->k1 + A->n_pad;
-            c->ev_valid = c->timing != 0;
+            c->R().ev_valid = c->timing != 0;
             c->last_f32_path = 0;
             return VSM_OK;
         }
@@ -691,13 +702,13 @@ int run_f32_knn(vsm_ctx* c, const DescSet* A, const DescSet* B, int metric, bool
     r->cidx = r->j1 + A->n_pad;
     r->ck = r->k1 + A->n_pad;
     const CoarseProblem p = make_problem(A, B, metric);
-    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
     HIPCHK(c, c->d_colpart.ensure(f32_scratch_bytes(p.pr, want_col)));
     launch_f32_knn(p.pr, r->j1, r->j2, r->k1, r->k2, want_col ? r->cidx : nullptr, want_col ? r->ck : nullptr,
                    c->d_colpart.p, c->stream);
     if (c->timing) {
-        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        c->ev_valid = true;
+        HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
+        c->R().ev_valid = true;
     }
     HIPCHK(c, hipGetLastError());
     c->last_f32_path = 1;
@@ -808,13 +819,14 @@ F32Rule make_f32_rule(const vsm_params* p, int metric)
 int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o)
 {
     const int npairs = (int)pl.pairs.size();
-    c->ev_valid = false;
-    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    c->R().ev_valid = false;
+    c->timing_slot = c->rs;
+    if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
     int rc = queue_coarse(c, pl.probs, pl.dim, 0);
     if (rc) return rc;
     if (c->timing) {
-        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        c->ev_valid = true;
+        HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
+        c->R().ev_valid = true;
     }
     for (F32PairRef& rf : pl.refs) {
         if (rf.fwd_off >= 0) rf.fwd_off = pl.probs[rf.fwd_off].out_off;
@@ -876,7 +888,8 @@ int f32_pairs_fast(vsm_ctx* c, const int32_t* pairs, int npairs, const vsm_param
     bool overflow = false;
     if ((rc = coarse_overflowed(c, &overflow)) != VSM_OK) return rc;
     if (overflow) {
-        c->ev_valid = false;
+        c->R().ev_valid = false;
+    c->timing_slot = c->rs;
         return VSM_OK;
     }
     c->last_f32_path = 0;
@@ -997,22 +1010,29 @@ extern "C" long long vsm_match_pairs(vsm_ctx* c, const int32_t* pairs, int npair
     int rc = check_params(c, p);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
-    // cut the list into submissions that fit the scratch budget
+    // cut the list into submissions that fit the scratch budget, of about equal scratch need
+    std::vector<size_t> need(npairs);
+    size_t need_total = 0;
+    for (int k = 0; k < npairs; ++k) {
+        const DescSet* A = get_set(c, pairs[2 * k]);
+        const DescSet* B = get_set(c, pairs[2 * k + 1]);
+        if (!A || !B) return fail(c, VSM_EINVAL, "pair %d names an unknown set", k);
+        const size_t chunks = ((size_t)B->n_pad + kChunkCols - 1) / kChunkCols;
+        need[k] = A->kind == SET_F32 ? ((size_t)A->n_pad + B->n_pad) * 2 * (kCoarseCap * 8 + 16 + 64)
+                                     : (chunks * A->n_pad + A->n) * kScratchPerRow;
+        need_total += need[k];
+    }
+    const size_t per_sub = std::max<size_t>(c->scratch_budget / 2, 1);
+    const size_t want_subs = std::max<size_t>((need_total + per_sub - 1) / per_sub, ((size_t)npairs + 8191) / 8192);
+    const size_t target = want_subs ? (need_total + want_subs - 1) / want_subs : 0;
     std::vector<int> cuts{0};
     while (cuts.back() < npairs) {
         const int done = cuts.back();
         size_t scratch = 0;
         int take = 0;
         while (done + take < npairs) {
-            const DescSet* A = get_set(c, pairs[2 * (done + take)]);
-            const DescSet* B = get_set(c, pairs[2 * (done + take) + 1]);
-            if (!A || !B) return fail(c, VSM_EINVAL, "pair %d names an unknown set", done + take);
-            const size_t chunks = ((size_t)B->n_pad + kChunkCols - 1) / kChunkCols;
-            const size_t need = A->kind == SET_F32
-                                    ? ((size_t)A->n_pad + B->n_pad) * 2 * (kCoarseCap * 8 + 16 + 64)
-                                    : (chunks * A->n_pad + A->n) * kScratchPerRow;
-            if (take > 0 && (scratch + need > c->scratch_budget / 2 || take >= 8192)) break;
-            scratch += need;
+            if (take > 0 && (scratch + need[done + take] > per_sub || scratch >= target || take >= 8192)) break;
+            scratch += need[done + take];
             ++take;
         }
         cuts.push_back(done + take);
@@ -1020,81 +1040,102 @@ extern "C" long long vsm_match_pairs(vsm_ctx* c, const int32_t* pairs, int npair
     const int nsub = (int)cuts.size() - 1;
     offsets[0] = 0;
     long long total = 0;
-    const DescSet* first = npairs > 0 ? get_set(c, pairs[0]) : nullptr;
-    if (!first || first->kind != SET_U8) {
-        // float pairs (and the empty list): one submission at a time
-        for (int k = 0; k < nsub; ++k) {
-            const int done = cuts[k], take = cuts[k + 1] - cuts[k];
-            const long long got = vsm_match_pairs_device(c, pairs + 2 * (size_t)done, take, p, metric);
-            if (got < 0) return got;
-            if (total + got > cap) return fail(c, VSM_ECAP, "more than %lld matches", cap);
-            std::vector<int64_t> off(take + 1);
-            const long long f = vsm_fetch_matches(c, off.data(), idx0 ? idx0 + total : nullptr,
-                                                  idx1 ? idx1 + total : nullptr, cap - total);
-            if (f < 0) return f;
-            for (int i = 0; i <= take; ++i) offsets[done + i] = total + off[i];
-            total += got;
-        }
-        return total;
-    }
-    // u8 pairs: submission k + 1 is queued before the lists of submission k are fetched, and the
-    // fetch runs on the copy stream, so the compute stream never waits for the host
-    const MatchRule rule = make_rule(p);
-    auto enqueue = [&](int k) -> int {
-        c->rs = k & 1;
-        Plan pl;
-        int r = plan_u8(c, pairs + 2 * (size_t)cuts[k], cuts[k + 1] - cuts[k], pl);
-        if (r) return r;
-        RunOpts o;
-        if ((r = run_u8(c, pl, rule, o)) != VSM_OK) return r;
-        HIPCHK(c, hipEventRecord(c->R().packed, c->stream));
-        return VSM_OK;
-    };
-    auto drain = [&]() {   // after a failure: nothing of this call may still be running
+    // submission k + 1 is queued before the lists of submission k are fetched, and the fetch runs on
+    // the copy stream, so the compute stream never waits for the host
+    if (c->inflight) return fail(c, VSM_EINVAL, "collect the submissions in flight first");
+    auto submit = [&](int k) { return vsm_submit_pairs(c, pairs + 2 * (size_t)cuts[k], cuts[k + 1] - cuts[k], p, metric); };
+    auto drain = [&]() {   // after a failure: nothing of this call may still be queued
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamSynchronize(c->copy_stream);
+        c->inflight = 0;
     };
-    if (nsub > 0 && (rc = enqueue(0)) != VSM_OK) return rc;
+    if (nsub > 0 && (rc = submit(0)) != VSM_OK) return rc;
     for (int k = 0; k < nsub; ++k) {
-        if (k + 1 < nsub && (rc = enqueue(k + 1)) != VSM_OK) {
+        if (k + 1 < nsub && (rc = submit(k + 1)) != VSM_OK) {
             drain();
             return rc;
         }
-        c->rs = k & 1;
-        vsm_ctx::ResultSlot& R = c->R();
         const int done = cuts[k], take = cuts[k + 1] - cuts[k];
-        hipError_t e = hipEventSynchronize(R.packed);
-        if (e == hipSuccess) e = R.h_off.ensure(sizeof(int64_t) * (take + 1));
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(R.h_off.p, R.d_offsets.p, sizeof(int64_t) * (take + 1), hipMemcpyDeviceToHost, c->copy_stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
-        if (e != hipSuccess) {
+        const long long got = vsm_collect_matches(c, offsets + done, idx0 ? idx0 + total : nullptr,
+                                                  idx1 ? idx1 + total : nullptr, cap - total);
+        if (got < 0) {
             drain();
-            return fail(c, VSM_ENODEV, "fetching match offsets: %s", hipGetErrorString(e));
+            return got;
         }
-        const int64_t* off = R.h_off.as<int64_t>();
-        const long long got = off[take];
-        if (total + got > cap) {
-            drain();
-            return fail(c, VSM_ECAP, "more than %lld matches", cap);
-        }
-        if (got > 0) {
-            if (idx0) e = hipMemcpyAsync(idx0 + total, R.d_tight0.p, sizeof(int32_t) * got, hipMemcpyDeviceToHost, c->copy_stream);
-            if (e == hipSuccess && idx1)
-                e = hipMemcpyAsync(idx1 + total, R.d_tight1.p, sizeof(int32_t) * got, hipMemcpyDeviceToHost, c->copy_stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
-            if (e != hipSuccess) {
-                drain();
-                return fail(c, VSM_ENODEV, "fetching match lists: %s", hipGetErrorString(e));
-            }
-        }
-        for (int i = 0; i <= take; ++i) offsets[done + i] = total + off[i];
+        for (int i = 0; i <= take; ++i) offsets[done + i] += total;
         total += got;
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->last_npairs = nsub > 0 ? cuts[nsub] - cuts[nsub - 1] : 0;
-    c->last_total = nsub > 0 ? c->R().h_off.as<int64_t>()[c->last_npairs] : 0;
     return total;
+}
+
+extern "C" int vsm_submit_pairs(vsm_ctx* c, const int32_t* pairs, int npairs, const vsm_params* p, int metric)
+{
+    if (!c) return VSM_EINVAL;
+    if (npairs < 0 || (npairs > 0 && !pairs)) return fail(c, VSM_EINVAL, "bad pair list");
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (c->inflight >= 2) return fail(c, VSM_EINVAL, "two submissions are in flight already: collect one first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int slot = (c->inflight_head + c->inflight) & 1;
+    const int timing_slot_before = c->timing_slot;
+    c->rs = slot;
+    const DescSet* first = npairs > 0 ? get_set(c, pairs[0]) : nullptr;
+    bool on_host = false;
+    if (first && first->kind == SET_F32) {
+        // float pairs are searched before this call returns (the survivor-overflow check needs the
+        // result); only the copy of the lists is left to vsm_collect_matches
+        if (c->inflight) return fail(c, VSM_EINVAL, "float submissions are not queued behind others: collect first");
+        RunOpts o;
+        bool done = false;
+        if ((rc = f32_pairs_fast(c, pairs, npairs, p, metric, o, &done)) != VSM_OK) return rc;
+        if (!done) {
+            const long long got = f32_pairs_slow(c, pairs, npairs, p, metric);
+            if (got < 0) return (int)got;
+            on_host = true;
+        }
+    } else {
+        Plan pl;
+        if ((rc = plan_u8(c, pairs, npairs, pl)) != VSM_OK) return rc;
+        RunOpts o;
+        if ((rc = run_u8(c, pl, make_rule(p), o)) != VSM_OK) return rc;
+    }
+    HIPCHK(c, hipEventRecord(c->R().packed, c->stream));
+    c->timing_slot = timing_slot_before;   // the brackets become readable once this submission is collected
+    c->inflight_pairs[slot] = npairs;
+    c->inflight_on_host[slot] = on_host;
+    ++c->inflight;
+    return VSM_OK;
+}
+
+extern "C" long long vsm_collect_matches(vsm_ctx* c, int64_t* offsets, int32_t* idx0, int32_t* idx1, long long cap)
+{
+    if (!c) return VSM_EINVAL;
+    if (!offsets) return fail(c, VSM_EINVAL, "offsets buffer is NULL");
+    if (c->inflight <= 0) return fail(c, VSM_EINVAL, "no submission in flight");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int slot = c->inflight_head;
+    const int npairs = c->inflight_pairs[slot];
+    c->inflight_head ^= 1;
+    --c->inflight;
+    c->rs = slot;
+    c->timing_slot = slot;
+    vsm_ctx::ResultSlot& R = c->R();
+    HIPCHK(c, hipEventSynchronize(R.packed));
+    HIPCHK(c, R.h_off.ensure(sizeof(int64_t) * (npairs + 1)));
+    HIPCHK(c, hipMemcpyAsync(R.h_off.p, R.d_offsets.p, sizeof(int64_t) * (npairs + 1), hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    const int64_t* off = R.h_off.as<int64_t>();
+    const long long got = off[npairs];
+    c->last_npairs = npairs;
+    c->last_total = got;
+    if (got > cap) return fail(c, VSM_ECAP, "%lld matches do not fit a buffer of %lld", got, cap);
+    if (got > 0) {
+        if (idx0) HIPCHK(c, hipMemcpyAsync(idx0, R.d_tight0.p, sizeof(int32_t) * got, hipMemcpyDeviceToHost, c->copy_stream));
+        if (idx1) HIPCHK(c, hipMemcpyAsync(idx1, R.d_tight1.p, sizeof(int32_t) * got, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    }
+    memcpy(offsets, off, sizeof(int64_t) * (npairs + 1));
+    return got;
 }
 
 extern "C" int vsm_match_pair(vsm_ctx* c, int set0, int set1, const vsm_params* p, int metric,
@@ -1253,6 +1294,8 @@ extern "C" int vsm_knn2(vsm_ctx* c, int set_q, int set_db, int metric,
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return A->n;
 }
+
+extern "C" int vsm_last_submission_pairs(const vsm_ctx* c) { return c ? c->slots[c->timing_slot].query_pairs : VSM_EINVAL; }
 
 extern "C" int vsm_set_scratch_budget(vsm_ctx* c, long long bytes)
 {

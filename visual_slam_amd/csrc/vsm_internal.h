@@ -23,7 +23,7 @@ constexpr int kDescDim = 128;
 constexpr int kRowPad = 512;
 constexpr int kTileBytes = 4096;      // 32 rows * 128 bytes
 constexpr int kStripRows = 512;       // query rows per workgroup of the query pass (4 waves * 128)
-constexpr int kVerifyBlock = 256;     // candidates per workgroup of the verify pass (8 waves * 32)
+constexpr int kVerifyBlock = 256;     // candidates per workgroup of the verify pass (4 waves * 64)
 constexpr int kStepRows = 256;        // streamed rows per main-loop step
 constexpr int kChunkCols = 8192;      // streamed rows per work item of the query-side pass
 constexpr int32_t kNormPad = 0x7FFFFF00;
