@@ -13,6 +13,8 @@
 //   4. confirm               keep candidates whose nearest image-0 row is the candidate itself
 #include "vsm_internal.h"
 
+#include <algorithm>
+
 namespace vsm {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -302,20 +304,22 @@ constexpr int kVerifyRB = kVerifyBlock / (32 * kVerifyWaves);
 
 __global__ __launch_bounds__(kVerifyWaves * 64, 2)
 void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ vitems,
-                        SiftCandidates cand, int negscale)
+                        const int* __restrict__ nvitems, SiftCandidates cand, int negscale)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const SiftItem it = vitems[xcd_contiguous_item(blockIdx.x, gridDim.x)];
-    const SiftPair pw = pairs[it.pair];
-    const int ncand = cand.count[it.pair];
-    const int cbase = it.strip * kVerifyBlock;
-    if (cbase >= ncand) return;  // uniform for the whole workgroup
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane5 = lane & 31;
     const int half = lane >> 5;
+    // The item list is built on the device (only blocks that hold candidates); a fixed grid walks it
+    // round-robin, so every workgroup leaves after at most ceil(total / gridDim.x) items.
+    const int total = *nvitems;
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    const SiftItem it = vitems[w];
+    const SiftPair pw = pairs[it.pair];
+    const int ncand = cand.count[it.pair];
+    const int cbase = it.strip * kVerifyBlock;
 
     int ci[kVerifyRB];
     v4i pf[kVerifyRB][4];
@@ -397,19 +401,57 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
         }
         if (half == 0 && ci[rb] < ncand) cand.vrow[pw.out0_off + ci[rb]] = bestrow[rb];
     }
+    }   // next work item (the last step's barrier separates it from this one's LDS reads)
 }
 
-void launch_sift_verify(const SiftPair* pairs, const SiftItem* vitems, int nvitems,
+// counts[pair] -> compact list of (pair, block of kVerifyBlock candidates), total in *nvitems
+__global__ __launch_bounds__(1024)
+void sift_verify_plan_kernel(const int32_t* __restrict__ counts, int npairs, SiftItem* __restrict__ vitems,
+                             int* __restrict__ nvitems)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < npairs; p0 += 1024) {
+        const int p = p0 + tid;
+        const int v = p < npairs ? (counts[p] + kVerifyBlock - 1) / kVerifyBlock : 0;
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) woff += wsum[w];
+            tot += wsum[w];
+        }
+        const int first = carry_s + woff + incl - v;
+        for (int b = 0; b < v; ++b) vitems[first + b] = SiftItem{p, (int16_t)b, 0};
+        __syncthreads();
+        if (tid == 0) carry_s += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *nvitems = carry_s;
+}
+
+
+void launch_sift_verify(const SiftPair* pairs, int npairs, SiftItem* vitems, int max_vitems, int* nvitems,
                         SiftCandidates cand, hipStream_t s)
 {
+    if (npairs <= 0 || max_vitems <= 0) return;
+    hipLaunchKernelGGL(sift_verify_plan_kernel, dim3(1), dim3(1024), 0, s, cand.count, npairs, vitems, nvitems);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sift_verify_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsStream);
         attr_set = true;
     }
-    hipLaunchKernelGGL(sift_verify_kernel, dim3(nvitems), dim3(kVerifyWaves * 64), kLdsStream, s,
-                       pairs, vitems, cand, -512);
+    hipLaunchKernelGGL(sift_verify_kernel, dim3(std::min(max_vitems, 1024)), dim3(kVerifyWaves * 64), kLdsStream, s,
+                       pairs, vitems, nvitems, cand, -512);
 }
 
 // ---- 2. select ---------------------------------------------------------------------------

@@ -174,7 +174,7 @@ constexpr size_t kScratchPerRow = 40;
 struct Plan {
     std::vector<SiftPair> pairs;
     std::vector<SiftItem> items;   // query pass: (pair, strip, chunk)
-    std::vector<SiftItem> vitems;  // verify pass: (pair, block of 256 candidates)
+    int max_vitems = 0;            // verify pass: blocks of kVerifyBlock candidates, at most
     size_t rows = 0, out0 = 0, out1 = 0;
 };
 
@@ -182,7 +182,7 @@ int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
 {
     pl.pairs.resize(npairs);
     pl.items.clear();
-    pl.vitems.clear();
+    pl.max_vitems = 0;
     for (int p = 0; p < npairs; ++p) {
         const DescSet* A = get_set(c, pairs[2 * p]);
         const DescSet* B = get_set(c, pairs[2 * p + 1]);
@@ -206,7 +206,7 @@ int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
         for (int s = 0; s < sp.nstrips; ++s)
             for (int ch = 0; ch < sp.nchunks; ++ch) pl.items.push_back(SiftItem{p, (int16_t)s, (int16_t)ch});
         if (!empty)
-            for (int vb = 0; vb * kVerifyBlock < A->n; ++vb) pl.vitems.push_back(SiftItem{p, (int16_t)vb, 0});
+            pl.max_vitems += (A->n + kVerifyBlock - 1) / kVerifyBlock;
     }
     if ((pl.rows + pl.out0) * kScratchPerRow > std::max(c->scratch_budget, kDefaultScratchBudget))
         return fail(c, VSM_EINVAL, "submission needs about %zu bytes of scratch (limit %zu); submit fewer pairs per call",
@@ -224,11 +224,11 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     const int npairs = (int)pl.pairs.size();
     const int nitems = (int)pl.items.size();
     c->R().query_pairs = npairs;
-    const int nvitems = rule.mutual ? (int)pl.vitems.size() : 0;
+    const int nvitems = rule.mutual ? pl.max_vitems : 0;
     HIPCHK(c, c->R().h_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
-    HIPCHK(c, c->R().h_items.ensure(sizeof(SiftItem) * std::max(nitems + nvitems, 1)));
+    HIPCHK(c, c->R().h_items.ensure(sizeof(SiftItem) * std::max(nitems, 1)));
     HIPCHK(c, c->d_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
-    HIPCHK(c, c->d_items.ensure(sizeof(SiftItem) * std::max(nitems + nvitems, 1)));
+    HIPCHK(c, c->d_items.ensure(sizeof(SiftItem) * std::max(nitems + nvitems, 1) + 64));
     const size_t rows = std::max<size_t>(pl.rows, 1);
     const size_t out0 = std::max<size_t>(pl.out0, 1), out1 = std::max<size_t>(pl.out1, 1);
     HIPCHK(c, c->d_rr1.ensure(rows * 4));
@@ -257,10 +257,9 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (npairs) memcpy(c->R().h_pairs.p, pl.pairs.data(), sizeof(SiftPair) * npairs);
     if (nitems) memcpy(c->R().h_items.p, pl.items.data(), sizeof(SiftItem) * nitems);
-    if (nvitems) memcpy(c->R().h_items.as<SiftItem>() + nitems, pl.vitems.data(), sizeof(SiftItem) * nvitems);
     if (npairs) HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->R().h_pairs.p, sizeof(SiftPair) * npairs, hipMemcpyHostToDevice, c->stream));
-    if (nitems + nvitems)
-        HIPCHK(c, hipMemcpyAsync(c->d_items.p, c->R().h_items.p, sizeof(SiftItem) * (nitems + nvitems), hipMemcpyHostToDevice, c->stream));
+    if (nitems)
+        HIPCHK(c, hipMemcpyAsync(c->d_items.p, c->R().h_items.p, sizeof(SiftItem) * nitems, hipMemcpyHostToDevice, c->stream));
 
     c->R().ev_valid = false;
     c->timing_slot = c->rs;
@@ -299,7 +298,8 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
                            c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, out, c->stream);
         if (nvitems) {
             if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev2, c->stream));
-            launch_sift_verify(c->d_pairs.as<SiftPair>(), c->d_items.as<SiftItem>() + nitems, nvitems, cand, c->stream);
+            launch_sift_verify(c->d_pairs.as<SiftPair>(), npairs, c->d_items.as<SiftItem>() + nitems, nvitems,
+                               reinterpret_cast<int*>(c->d_items.as<SiftItem>() + nitems + nvitems), cand, c->stream);
             if (c->timing) {
                 HIPCHK(c, hipEventRecord(c->R().ev3, c->stream));
                 c->R().ev_verify_valid = true;

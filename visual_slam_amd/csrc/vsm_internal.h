@@ -125,8 +125,10 @@ void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
 void launch_sift_select(const SiftPair* pairs, int npairs, const int32_t* rr_d1, const int32_t* rr_j1,
                         const int32_t* rr_d2, MatchRule rule, SiftCandidates cand, SiftOutputs out,
                         hipStream_t s);
-// mutual check: nearest image-0 row of every candidate's train row
-void launch_sift_verify(const SiftPair* pairs, const SiftItem* vitems, int nvitems,
+// mutual check: nearest image-0 row of every candidate's train row.  vitems (room for max_vitems =
+// sum over pairs of ceil(nA / kVerifyBlock) entries) and *nvitems are device scratch: the list of
+// candidate blocks is built on the device from the candidate counts.
+void launch_sift_verify(const SiftPair* pairs, int npairs, SiftItem* vitems, int max_vitems, int* nvitems,
                         SiftCandidates cand, hipStream_t s);
 // keeps the confirmed candidates, writes compact and dense outputs
 void launch_sift_confirm(const SiftPair* pairs, int npairs, SiftCandidates cand, int mutual,
