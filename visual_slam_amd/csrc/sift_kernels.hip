@@ -68,10 +68,10 @@ void launch_sift_transform(const uint8_t* des, int n, int n_pad, int8_t* frag, i
 // ---------------------------------------------------------------------------------
 // streaming MFMA passes
 // ---------------------------------------------------------------------------------
-// Workgroup = 8 waves.  Wave w keeps the MFMA operand of 32 "persistent" rows in registers;
-// the other set streams through LDS in 256-row steps (32 KiB, already in operand order in
-// HBM, copied by LDS-DMA, double buffered), and every wave multiplies its 32 rows by all eight
-// 32-row tiles of the step.
+// Workgroup = 4 waves.  Each wave keeps the MFMA operands of a few blocks of 32 "persistent"
+// rows in registers; the other set streams through LDS in 256-row steps (32 KiB, already in
+// operand order in HBM, copied by LDS-DMA, double buffered), and every wave multiplies its
+// blocks by all eight 32-row tiles of the step, reading each tile from LDS once.
 //
 // The persistent rows sit on the accumulator's LANE axis (they are the B operand): lane l owns
 // persistent row (l & 31), and its 16 accumulator registers hold streamed rows
