@@ -269,6 +269,16 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
                         const float x = acc[rb][reg];
                         if (x >= thr[rb]) {   // padding rows (-inf) get in only while thr is -inf; the re-rank drops them
                             const int rin = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                            if (cnt[rb] == kCoarseCap) {
+                                // full: the threshold has risen since the early entries went in, and an
+                                // entry below the present threshold can never be a survivor; drop those
+                                int kept = 0;
+                                for (int e = 0; e < kCoarseCap; ++e) {
+                                    const uint2 en = mylist[e];
+                                    if (__uint_as_float(en.y) >= thr[rb]) mylist[kept++] = en;
+                                }
+                                cnt[rb] = kept;
+                            }
                             if (cnt[rb] < kCoarseCap)
                                 mylist[cnt[rb]] = make_uint2((unsigned)(tile * 32 + rin), __float_as_uint(x));
                             ++cnt[rb];
