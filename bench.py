@@ -445,16 +445,22 @@ def run_db_query(args, torch, dist, world, rank):
     m.set_f32_mode(args.f32_mode)
     base = np.asarray([min(ndb, r * per) for r in range(world + 1)], np.int64)
 
+    # per-slice result stays on the device: 4 x nq words (keys as float bits, slice-local rows), all-gathered
+    # over RCCL and merged by a kernel (key, then global row); only the merged lists travel to the host
+    pack = torch.empty((4, nq), dtype=torch.int32, device="cuda")
+    allp = torch.empty((world, 4, nq), dtype=torch.int32, device="cuda") if world > 1 else pack
+
     def step():
-        i1, i2, k1, k2 = m.knn2(sq, sdb, vsm.METRIC_L2, want_idx2=True)
-        if world == 1:
-            return B.merge_top2_f32(k1[None], k2[None], i1[None], i2[None], base, vsm.METRIC_L2)
-        pack = torch.from_numpy(np.stack([k1.view(np.int32), k2.view(np.int32), i1, i2])).to(comm_device())
-        allp = [torch.empty_like(pack) for _ in range(world)]
-        dist.all_gather(allp, pack)
-        allp = torch.stack(allp).cpu().numpy()
-        return B.merge_top2_f32(allp[:, 0].view(np.float32), allp[:, 1].view(np.float32), allp[:, 2], allp[:, 3],
-                                base, vsm.METRIC_L2)
+        m.knn2_device(sq, sdb, vsm.METRIC_L2, pack.data_ptr())
+        if world > 1:
+            if REHEARSAL:
+                parts = [torch.empty((4, nq), dtype=torch.int32) for _ in range(world)]
+                dist.all_gather(parts, pack.cpu())
+                allp.copy_(torch.stack(parts))
+            else:
+                dist.all_gather_into_tensor(allp, pack)
+            torch.cuda.synchronize()
+        return m.merge_top2_device(allp.data_ptr(), base, world, nq, vsm.METRIC_L2)
 
     for _ in range(args.warmup):
         step()
@@ -475,7 +481,7 @@ def run_db_query(args, torch, dist, world, rank):
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "16384 float-256 queries vs 1M-row database, k=2, L2",
-                   "parallelism": "database sliced x%d + all-gather + merge" % world},
+                   "parallelism": "database sliced x%d, RCCL all-gather of the per-slice 2-NN lists, device merge" % world},
         "roofline": f32_roofline(m, OPS_PER_EVAL_F32 * float(nq) * (hi - lo), kms),
     }
     m.close()

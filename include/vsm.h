@@ -142,6 +142,15 @@ int vsm_knn2(vsm_ctx* ctx, int set_q, int set_db, int metric,
 int vsm_merge_top2_f32(const float* k1, const float* k2, const int32_t* i1, const int32_t* i2,
                        const int64_t* base, int nslices, int nq, int metric,
                        float* ok1, float* ok2, int64_t* oi1, int64_t* oi2);
+/* The same two steps without the host in between, for a database sliced over GPUs: vsm_knn2_device
+ * leaves one slice's result in a caller-owned device buffer of 4 * nq 32-bit words (best key,
+ * runner-up key as float bits, best row, runner-up row; float sets only) that can go straight into an
+ * all-gather; vsm_merge_top2_device merges the gathered [nslices][4][nq] buffer on the device and
+ * returns the global lists.  The caller orders its own stream against these calls (both return
+ * after their work has finished). */
+int vsm_knn2_device(vsm_ctx* ctx, int set_q, int set_db, int metric, void* packed_dev);
+int vsm_merge_top2_device(vsm_ctx* ctx, const void* packed_dev, const int64_t* base, int nslices, int nq,
+                          int metric, float* ok1, float* ok2, int64_t* oi1, int64_t* oi2);
 /* NearestEmbedFunc.forward (model_2_0.py:43-78): x [batch][dim][npts], emb [dim][k];
  * argmin [batch][npts] int64, result (may be NULL) [batch][dim][npts]. */
 int vsm_nearest_embed(vsm_ctx* ctx, const float* x, int batch, int dim, int npts,

@@ -218,3 +218,42 @@ def test_full_survivor_list_drops_stale_entries(matcher, f32_mode):
     b = (c * a[0] + np.sqrt(1.0 - c * c) * r).astype(np.float32)
     _knn_check(matcher, a, b, vsm.METRIC_DOT)
     assert matcher.last_f32_path() == f32_mode
+
+
+def test_device_merge_equals_host_merge(matcher):
+    """Per-slice results left on the device and merged by the kernel = the host merge = the whole database."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")          # the runtime the library already loaded
+    rng = np.random.default_rng(61)
+    q = synth.unit_f32(500, 256, rng)
+    db = synth.unit_f32(3000, 256, rng)
+    db[2500] = db[20]
+    db[700] = q[5]
+    db[2900] = q[5]
+    cuts = [0, 512, 1100, 1100, 2000, 3000]      # one empty slice
+    ns, nq = len(cuts) - 1, len(q)
+    sq = matcher.upload_f32(q)
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), C.c_size_t(ns * 4 * nq * 4)) == 0
+    try:
+        for metric in (vsm.METRIC_L2, vsm.METRIC_DOT):
+            for s_, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+                sd = matcher.upload_f32(db[lo:hi])
+                matcher.knn2_device(sq, sd, metric, dev.value + s_ * 4 * nq * 4)
+                matcher.release(sd)
+            k1, k2, i1, i2 = matcher.merge_top2_device(dev.value, np.asarray(cuts, np.int64), ns, nq, metric)
+            h = np.empty((ns, 4, nq), np.int32)
+            assert hip.hipMemcpy(h.ctypes.data_as(C.c_void_p), dev, C.c_size_t(h.nbytes), 2) == 0
+            hk1, hk2, hi1, hi2 = B.merge_top2_f32(h[:, 0].view(np.float32), h[:, 1].view(np.float32), h[:, 2], h[:, 3],
+                                                  np.asarray(cuts, np.int64), metric)
+            np.testing.assert_array_equal(i1, hi1)
+            np.testing.assert_array_equal(i2, hi2)
+            np.testing.assert_array_equal(k1, hk1)
+            np.testing.assert_array_equal(k2, hk2)
+            oi, o1, o2 = orc.knn2_f32(q, db, metric)
+            np.testing.assert_array_equal(i1, oi)
+            np.testing.assert_array_equal(k1, o1)
+            np.testing.assert_array_equal(k2, o2)
+    finally:
+        hip.hipFree(dev)
+        matcher.release(sq)

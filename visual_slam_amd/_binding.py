@@ -68,6 +68,9 @@ SIGNATURES = {
     "vsm_match_pairs_device": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Params), C.c_int]),
     "vsm_fetch_matches": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]),
     "vsm_knn2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsm_knn2_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vsm_merge_top2_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsm_merge_top2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsm_nearest_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -279,6 +282,19 @@ class Matcher:
         if want_idx2:
             return idx1[:nq], idx2[:nq], d1[:nq], d2[:nq]
         return idx1[:nq], d1[:nq], d2[:nq]
+
+    def knn2_device(self, set_q, set_db, metric, packed_ptr):
+        """2-NN of a float query set in one database slice, left in a device buffer of 4 * nq int32 words."""
+        return self._check(self._l.vsm_knn2_device(self._h, set_q, set_db, metric, C.c_void_p(int(packed_ptr))))
+
+    def merge_top2_device(self, gathered_ptr, base, nslices, nq, metric):
+        """Device merge of an all-gathered [nslices][4][nq] buffer; returns (k1, k2, i1, i2) on the host."""
+        base = np.ascontiguousarray(base, np.int64)
+        ok1, ok2 = np.empty(nq, np.float32), np.empty(nq, np.float32)
+        oi1, oi2 = np.empty(nq, np.int64), np.empty(nq, np.int64)
+        self._check(self._l.vsm_merge_top2_device(self._h, C.c_void_p(int(gathered_ptr)), _ptr(base), nslices, nq, metric,
+                                                  _ptr(ok1), _ptr(ok2), _ptr(oi1), _ptr(oi2)))
+        return ok1, ok2, oi1, oi2
 
     def nearest_embed(self, x, emb, want_result=True):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -73,4 +73,43 @@ void launch_f32_accept(const SiftPair* pairs, const F32PairRef* refs, int npairs
     hipLaunchKernelGGL(f32_accept_kernel, dim3(npairs), dim3(1024), 0, s, pairs, refs, rule, j1, k1, k2, out);
 }
 
+// ---- merge of per-slice 2-NN lists (database cut into contiguous row ranges) ---------------
+// packed: [nslices][4][nq] 32-bit words = best key, runner-up key (float bits), best row, runner-up
+// row (slice-local, -1 = none).  Order: key, then global row (lower first), as on the host.
+__global__ void merge_top2_kernel(const int32_t* __restrict__ packed, const int64_t* __restrict__ base,
+                                  int nslices, int nq, int metric, float* __restrict__ ok1,
+                                  float* __restrict__ ok2, int64_t* __restrict__ oi1, int64_t* __restrict__ oi2)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const bool dot = metric == 0;
+    float b1 = 0.0f, b2 = 0.0f;
+    int64_t x1 = -1, x2 = -1;
+    for (int s = 0; s < nslices; ++s) {
+        const int32_t* sl = packed + (size_t)s * 4 * nq;
+        for (int r = 0; r < 2; ++r) {
+            const int32_t li = sl[(size_t)(2 + r) * nq + q];
+            if (li < 0) continue;
+            const float k = __int_as_float(sl[(size_t)r * nq + q]);
+            const int64_t id = base[s] + li;
+            const bool beats1 = x1 < 0 || (dot ? k > b1 : k < b1) || (k == b1 && id < x1);
+            if (beats1) {
+                b2 = b1; x2 = x1;
+                b1 = k; x1 = id;
+            } else if (x2 < 0 || (dot ? k > b2 : k < b2) || (k == b2 && id < x2)) {
+                b2 = k; x2 = id;
+            }
+        }
+    }
+    ok1[q] = b1; ok2[q] = b2; oi1[q] = x1; oi2[q] = x2;
+}
+
+void launch_merge_top2(const int32_t* packed, const int64_t* base, int nslices, int nq, int metric,
+                       float* ok1, float* ok2, int64_t* oi1, int64_t* oi2, hipStream_t s)
+{
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(merge_top2_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, packed, base, nslices, nq, metric,
+                       ok1, ok2, oi1, oi2);
+}
+
 }  // namespace vsm

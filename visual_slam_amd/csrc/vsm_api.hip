@@ -1315,6 +1315,63 @@ extern "C" int vsm_set_f32_mode(vsm_ctx* c, int mode)
 
 extern "C" int vsm_last_f32_path(const vsm_ctx* c) { return c ? c->last_f32_path : VSM_EINVAL; }
 
+extern "C" int vsm_knn2_device(vsm_ctx* c, int set_q, int set_db, int metric, void* packed_dev)
+{
+    if (!c) return VSM_EINVAL;
+    if (!packed_dev) return fail(c, VSM_EINVAL, "output buffer is NULL");
+    SetKind kind;
+    int rc = set_kind_of_pair(c, set_q, set_db, &kind);
+    if (rc) return rc;
+    if (kind != SET_F32) return fail(c, VSM_EUNSUPPORTED, "vsm_knn2_device takes float sets");
+    HIPCHK(c, hipSetDevice(c->device));
+    const DescSet* A = get_set(c, set_q);
+    const DescSet* B = get_set(c, set_db);
+    const size_t nq = (size_t)A->n;
+    if (nq == 0) return 0;
+    int32_t* out = static_cast<int32_t*>(packed_dev);
+    if (B->n == 0) {
+        HIPCHK(c, hipMemsetAsync(out, 0, nq * 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(out + 2 * nq, 0xFF, nq * 8, c->stream));   // rows = -1
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return A->n;
+    }
+    F32Result r;
+    if ((rc = run_f32_knn(c, A, B, metric, false, &r)) != VSM_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, r.k1, nq * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out + nq, r.k2, nq * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out + 2 * nq, r.j1, nq * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out + 3 * nq, r.j2, nq * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return A->n;
+}
+
+extern "C" int vsm_merge_top2_device(vsm_ctx* c, const void* packed_dev, const int64_t* base, int nslices, int nq,
+                                     int metric, float* ok1, float* ok2, int64_t* oi1, int64_t* oi2)
+{
+    if (!c) return VSM_EINVAL;
+    if (!packed_dev || !base || nslices <= 0 || nq < 0 || !ok1 || !ok2 || !oi1 || !oi2) return fail(c, VSM_EINVAL, "bad argument");
+    if (nq == 0) return VSM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    // workspace: base[nslices + 1], then the four outputs
+    const size_t base_bytes = ((size_t)(nslices + 1) * 8 + 255) & ~(size_t)255;
+    HIPCHK(c, c->d_stage.ensure(base_bytes + (size_t)nq * 24));
+    char* ws = c->d_stage.as<char>();
+    int64_t* d_base = reinterpret_cast<int64_t*>(ws);
+    int64_t* d_i1 = reinterpret_cast<int64_t*>(ws + base_bytes);
+    int64_t* d_i2 = d_i1 + nq;
+    float* d_k1 = reinterpret_cast<float*>(d_i2 + nq);
+    float* d_k2 = d_k1 + nq;
+    HIPCHK(c, hipMemcpyAsync(d_base, base, (size_t)(nslices + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    launch_merge_top2(static_cast<const int32_t*>(packed_dev), d_base, nslices, nq, metric, d_k1, d_k2, d_i1, d_i2, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(ok1, d_k1, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ok2, d_k2, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(oi1, d_i1, (size_t)nq * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(oi2, d_i2, (size_t)nq * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VSM_OK;
+}
+
 extern "C" int vsm_merge_top2_f32(const float* k1, const float* k2, const int32_t* i1, const int32_t* i2,
                                   const int64_t* base, int nslices, int nq, int metric,
                                   float* ok1, float* ok2, int64_t* oi1, int64_t* oi2)

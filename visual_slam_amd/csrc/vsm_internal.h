@@ -116,6 +116,10 @@ struct F32Rule {
 void launch_f32_accept(const SiftPair* pairs, const F32PairRef* refs, int npairs, F32Rule rule,
                        const int32_t* j1, const float* k1, const float* k2, SiftOutputs out, hipStream_t s);
 
+// device merge of per-slice 2-NN lists; packed = [nslices][4][nq] words (key1, key2, row1, row2)
+void launch_merge_top2(const int32_t* packed, const int64_t* base, int nslices, int nq, int metric,
+                       float* ok1, float* ok2, int64_t* oi1, int64_t* oi2, hipStream_t s);
+
 void launch_sift_transform(const uint8_t* des, int n, int n_pad, int8_t* frag, int32_t* nrm8c,
                            hipStream_t s);
 // query-side pass: per (chunk, query row) best train row, its distance, runner-up distance
