@@ -220,6 +220,72 @@ def test_full_survivor_list_drops_stale_entries(matcher, f32_mode):
     assert matcher.last_f32_path() == f32_mode
 
 
+@pytest.mark.parametrize("metric,ratio,mutual,dim", [(vsm.METRIC_DOT, None, True, 256), (vsm.METRIC_L2, 0.8, True, 256),
+                                                     (vsm.METRIC_L2, 0.9, False, 256), (vsm.METRIC_DOT, None, True, 64),
+                                                     (vsm.METRIC_L2, 0.8, True, 100)])
+def test_float_pairs_in_one_submission(matcher, metric, ratio, mutual, dim):
+    """Many float pairs per call (ragged sizes, an empty set, a one-row set) against the oracle pair by
+    pair.  The submission is large enough for the eight-queries-per-wave re-rank kernel; single pairs
+    elsewhere in this file run the wave-per-query one."""
+    rng = np.random.default_rng(41)
+    sizes = [700, 513, 0, 900, 1, 1100, 256]
+    pool = synth.unit_f32(600, dim, rng)
+    imgs = []
+    for n in sizes:
+        d = synth.unit_f32(max(n, 1), dim, rng)[:n]
+        k = min(n, 600) // 2
+        if k:
+            noisy = pool[rng.choice(600, k, replace=False)] + 0.8 / math.sqrt(dim) * rng.standard_normal((k, dim)).astype(np.float32)
+            d[rng.choice(n, k, replace=False)] = noisy / np.linalg.norm(noisy, axis=1, keepdims=True)
+        imgs.append(np.ascontiguousarray(d, np.float32))
+    ids = [matcher.upload_f32(d) for d in imgs]
+    pairs = [(a, b) for a in range(len(sizes)) for b in range(len(sizes)) if a != b][:30]
+    pr = np.asarray([[ids[a], ids[b]] for a, b in pairs], np.int32)
+    off, i0, i1 = matcher.match_pairs(pr, ratio=ratio, mutual=mutual, metric=metric, min_score=0.5)
+    fr = None if ratio is None else tuple(B.ratio_to_fraction(ratio))
+    total = 0
+    for k, (a, b) in enumerate(pairs):
+        o0, _, _, _ = orc.match_dense_f32(imgs[a], imgs[b], metric, orc.params(fr, mutual, min_score=0.5))
+        want0 = np.nonzero(o0 >= 0)[0]
+        np.testing.assert_array_equal(i0[off[k]:off[k + 1]], want0)
+        np.testing.assert_array_equal(i1[off[k]:off[k + 1]], o0[want0])
+        total += len(want0)
+    assert off[-1] == total and total > 500
+    for sid in ids:
+        matcher.release(sid)
+
+
+def test_database_query_full_size_both_paths_agree(matcher, f32_mode):
+    """16384 queries against 1 M rows (the localisation-query shape): the bf16 + re-rank path and the
+    f32 matrix-core kernel must return the same bits; a 64-query sample is checked against the oracle."""
+    if f32_mode != vsm.F32_FAST_EXACT:
+        pytest.skip("one comparison covers both paths")
+    rng = np.random.default_rng(51)
+    q = synth.unit_f32(16384, 256, rng)
+    db = rng.standard_normal((1000000, 256), dtype=np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    db[777777] = q[5]
+    db[12] = q[5]
+    sq, sd = matcher.upload_f32(q), matcher.upload_f32(db)
+    try:
+        fast = matcher.knn2(sq, sd, vsm.METRIC_L2, want_idx2=True)
+        assert matcher.last_f32_path() == vsm.F32_FAST_EXACT
+        matcher.set_f32_mode(vsm.F32_MFMA_F32)
+        exact = matcher.knn2(sq, sd, vsm.METRIC_L2, want_idx2=True)
+        assert matcher.last_f32_path() == vsm.F32_MFMA_F32
+        for f, e in zip(fast, exact):
+            np.testing.assert_array_equal(f, e)
+        assert fast[0][5] == 12 and fast[1][5] == 777777
+        oi, ok1, ok2 = orc.knn2_f32(q[:64], db, orc.METRIC_L2)
+        np.testing.assert_array_equal(fast[0][:64], oi)
+        np.testing.assert_array_equal(fast[2][:64], ok1)
+        np.testing.assert_array_equal(fast[3][:64], ok2)
+    finally:
+        matcher.set_f32_mode(vsm.F32_FAST_EXACT)
+        matcher.release(sq)
+        matcher.release(sd)
+
+
 def test_device_merge_equals_host_merge(matcher):
     """Per-slice results left on the device and merged by the kernel = the host merge = the whole database."""
     import ctypes as C

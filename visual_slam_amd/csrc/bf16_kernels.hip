@@ -489,6 +489,132 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
     }
 }
 
+// The same re-rank for submissions of many small problems (few sublists per query, millions of
+// queries): eight queries per wave, one per group of eight lanes, so that a wave's memory round trips
+// (coarse results, list entries, surviving rows) serve eight queries at a time.  Lane `sub` of a group
+// keeps columns [sub * DIMP/8, (sub + 1) * DIMP/8) of its query in registers and reads the same columns
+// of a surviving row; the chain is handed through the group as above.  Results are bit-identical to
+// bf16_rerank_kernel.  Groups whose query lies past the end of the set leave at once; every shuffle below
+// stays inside one group.
+constexpr int kGroupWaves = 4;
+constexpr int kGroupQueries = kGroupWaves * 8;   // queries per workgroup
+
+template <int DIMP>
+__global__ __launch_bounds__(kGroupWaves * 64)
+void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
+                              const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
+                              int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
+                              float* __restrict__ k1_all, float* __restrict__ k2_all)
+{
+    constexpr int Q = DIMP / 32;   // float4 pieces of a row per lane
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int sub = lane & 7, gbase = lane & ~7;
+    const CoarseProblem& P = probs[blockIdx.y];
+    const F32Problem pr = P.pr;
+    const int i = ((int)blockIdx.x * kGroupWaves + wave) * 8 + (lane >> 3);
+    if (i >= pr.nA) return;
+    const int nsub = P.nsplits * 2;
+    const CoarsePart* __restrict__ part = part_all + P.part_off;
+    const uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
+    auto sub_index = [&](int sid) { return ((size_t)(sid >> 1) * pr.nA_pad + i) * 2 + (sid & 1); };
+
+    float4 a[Q];
+    {
+        const float4* pa = reinterpret_cast<const float4*>(P.rowsA + (size_t)i * DIMP) + sub * Q;
+#pragma unroll
+        for (int u = 0; u < Q; ++u) a[u] = pa[u];
+    }
+    const bool l2 = pr.metric == 1;
+    const float na = pr.nrmA[i];
+    const float margin = coarse_margin(l2, na, *P.maxnormB_sq);
+
+    // final coarse runner-up over all splits and both lane halves
+    float T1 = -INFINITY, T2 = -INFINITY;
+    int cnt_first = 0;
+    for (int sid = sub; sid < nsub; sid += 8) {
+        const CoarsePart cp = part[sub_index(sid)];
+        T2 = fmaxf(fmaxf(T2, cp.t2), fminf(T1, cp.t1));
+        T1 = fmaxf(T1, cp.t1);
+        if (sid == sub) cnt_first = cp.count;
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+        const float o1 = __shfl_xor(T1, m), o2 = __shfl_xor(T2, m);
+        T2 = fmaxf(fmaxf(T2, o2), fminf(T1, o1));
+        T1 = fmaxf(T1, o1);
+    }
+    const float thr = T2 - margin;
+
+    Best2 best;   // the same in every lane of the group
+    best.s1 = -INFINITY; best.s2 = -INFINITY; best.r1 = -1; best.r2 = -1;
+    for (int chunk = 0; chunk < nsub; chunk += 8) {
+        const int sid = chunk + sub;
+        const int cnt = chunk == 0 ? cnt_first : (sid < nsub ? part[sub_index(sid)].count : 0);
+        int incl = cnt;   // inclusive prefix sum of the chunk's list lengths, within the group
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) {
+            const int o = __shfl(incl, max(lane - d, gbase));
+            if (sub >= d) incl += o;
+        }
+        const int total = __shfl(incl, gbase + 7);
+        for (int e0 = 0; e0 < total; e0 += 8) {
+            const int e = e0 + sub;
+            int lo = 0;   // sublist of flat entry e: the first lane whose inclusive prefix exceeds e
+#pragma unroll
+            for (int step = 4; step >= 1; step >>= 1) {
+                const int probe = __shfl(incl, gbase + lo + step - 1);
+                if (probe <= e) lo += step;
+            }
+            lo = min(lo, 7);
+            const int within = e - (__shfl(incl, gbase + lo) - __shfl(cnt, gbase + lo));
+            bool keep = false;
+            int row = 0;
+            if (e < total) {
+                const uint2 en = lists[sub_index(chunk + lo) * kCoarseCap + within];
+                row = (int)en.x;
+                keep = __uint_as_float(en.y) >= thr && row < pr.nB;
+            }
+            unsigned m = (unsigned)(__ballot(keep) >> gbase) & 0xffu;   // this group's survivors
+            while (m) {
+                const int bit = __ffs(m) - 1;
+                m &= m - 1;
+                const int r = __shfl(row, gbase + bit);
+                const float4* pb = reinterpret_cast<const float4*>(P.rowsB + (size_t)r * DIMP) + sub * Q;
+                float4 b[Q];
+#pragma unroll
+                for (int u = 0; u < Q; ++u) b[u] = pb[u];
+                const float nbr = pr.nrmB[r];
+                float d = 0.0f;
+#pragma unroll
+                for (int stage = 0; stage < 8; ++stage) {
+                    if (sub == stage) {
+#pragma unroll
+                        for (int u = 0; u < Q; ++u) {
+                            d = fmaf(b[u].x, a[u].x, d);
+                            d = fmaf(b[u].y, a[u].y, d);
+                            d = fmaf(b[u].z, a[u].z, d);
+                            d = fmaf(b[u].w, a[u].w, d);
+                        }
+                    }
+                    const float handed = __shfl(d, gbase + stage);
+                    if (sub == stage + 1) d = handed;
+                    if (stage == 7) d = handed;   // the finished chain, in every lane of the group
+                }
+                const float sc = l2 ? fmaf(2.0f, d, -nbr) : d;
+                if (sc > -INFINITY) best2_insert(best, sc, r);
+            }
+        }
+    }
+    if (sub == 0) {
+        const int64_t o = P.out_off + i;
+        j1_all[o] = best.r1;
+        j2_all[o] = best.r2;
+        k1_all[o] = best.r1 < 0 ? (l2 ? INFINITY : -INFINITY) : (l2 ? fmaxf(-best.s1 + na, 0.0f) : best.s1);
+        k2_all[o] = best.r2 < 0 ? (l2 ? INFINITY : -INFINITY) : (l2 ? fmaxf(-best.s2 + na, 0.0f) : best.s2);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // planning and launch
 // ---------------------------------------------------------------------------------
@@ -514,6 +640,7 @@ CoarseTotals plan_coarse(CoarseProblem* probs, int n, int target_wgs)
         p.out_off = t.out_rows;
         t.coarse_blocks += p.nstrips * p.nsplits;
         t.rerank_blocks = std::max(t.rerank_blocks, (p.pr.nA + kRerankWaves - 1) / kRerankWaves);
+        t.max_nsplits = std::max(t.max_nsplits, p.nsplits);
         t.sublists += (int64_t)p.nsplits * p.pr.nA_pad * 2;
         t.out_rows += p.pr.nA_pad;
     }
@@ -553,7 +680,17 @@ void launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const 
     if (dimp == 64) launch_coarse_t<64>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
     else if (dimp == 128) launch_coarse_t<128>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
     else launch_coarse_t<256>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
-    if (t.rerank_blocks > 0) {
+    if (t.rerank_blocks <= 0) return;
+    // many queries with few sublists each: eight queries per wave; few queries with many sublists
+    // (a sliced database): one wave per query
+    const bool grouped = t.max_nsplits * 2 <= 16 && (int64_t)t.rerank_blocks * nprobs >= 4096;
+    if (grouped) {
+        const int per = kGroupQueries / kRerankWaves;
+        const dim3 grid((t.rerank_blocks + per - 1) / per, nprobs), block(kGroupWaves * 64);
+        if (dimp == 64) hipLaunchKernelGGL(bf16_rerank_group_kernel<64>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+        else if (dimp == 128) hipLaunchKernelGGL(bf16_rerank_group_kernel<128>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+        else hipLaunchKernelGGL(bf16_rerank_group_kernel<256>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+    } else {
         const dim3 grid(t.rerank_blocks, nprobs), block(kRerankWaves * 64);
         if (dimp == 64) hipLaunchKernelGGL(bf16_rerank_kernel<64>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
         else if (dimp == 128) hipLaunchKernelGGL(bf16_rerank_kernel<128>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);

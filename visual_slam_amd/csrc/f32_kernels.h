@@ -97,6 +97,7 @@ struct CoarseProblem {
 struct CoarseTotals {
     int coarse_blocks = 0;
     int rerank_blocks = 0;   // query blocks of the largest problem (grid x of the re-rank)
+    int max_nsplits = 0;     // most database splits any problem has (picks the re-rank kernel)
     int64_t sublists = 0, out_rows = 0;
 };
 

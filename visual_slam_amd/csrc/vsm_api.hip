@@ -889,12 +889,52 @@ int f32_pairs_fast(vsm_ctx* c, const int32_t* pairs, int npairs, const vsm_param
     if ((rc = coarse_overflowed(c, &overflow)) != VSM_OK) return rc;
     if (overflow) {
         c->R().ev_valid = false;
-    c->timing_slot = c->rs;
         return VSM_OK;
     }
     c->last_f32_path = 0;
     *done = true;
     return VSM_OK;
+}
+
+// One float pair, lists or dense forms straight into the caller's buffers with a single wait: the
+// coarse / re-rank / accept kernels, the overflow flag and the result copies are queued together, and
+// the flag is looked at after the one synchronisation.  Returns the match count, or VSM_EUNSUPPORTED - 1000
+// ("not done") when the context is in f32-only mode or a survivor list overflowed.
+constexpr int kNotDone = -1000;
+int f32_single_pair_fast(vsm_ctx* c, const DescSet* A, const DescSet* B, int set0, int set1, const vsm_params* p,
+                         int metric, int32_t* idx0, int32_t* idx1, float* dist, int cap, int32_t* dense0,
+                         int32_t* dense1)
+{
+    if (c->f32_mode != 0) return kNotDone;
+    const int32_t one[2] = {set0, set1};
+    F32Plan pl;
+    int rc = plan_f32(c, one, 1, metric, p->mutual != 0, pl);
+    if (rc) return rc;
+    RunOpts o;
+    o.want_pack = false;
+    o.want_dist = dist != nullptr;
+    o.want_dense = dense0 != nullptr;
+    if ((rc = run_f32_batch(c, pl, make_f32_rule(p, metric), o)) != VSM_OK) return rc;
+    int* flag = c->h_small.as<int>() + 8;
+    int32_t* cnt = c->h_small.as<int32_t>();
+    HIPCHK(c, hipMemcpyAsync(flag, c->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    const size_t take = (size_t)std::min(std::max(cap, 0), A->n);   // a pair has at most nA matches
+    if (take) {
+        if (idx0) HIPCHK(c, hipMemcpyAsync(idx0, c->d_slot0.p, take * 4, hipMemcpyDeviceToHost, c->stream));
+        if (idx1) HIPCHK(c, hipMemcpyAsync(idx1, c->d_slot1.p, take * 4, hipMemcpyDeviceToHost, c->stream));
+        if (dist) HIPCHK(c, hipMemcpyAsync(dist, c->d_slotd.p, take * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (dense0 && A->n) HIPCHK(c, hipMemcpyAsync(dense0, c->d_dense0.p, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
+    if (dense1 && B->n) HIPCHK(c, hipMemcpyAsync(dense1, c->d_dense1.p, sizeof(int32_t) * B->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    if (*flag != 0) {
+        c->R().ev_valid = false;
+        return kNotDone;
+    }
+    c->last_f32_path = 0;
+    return *cnt;
 }
 
 // Per-pair path on the f32 kernel; leaves offsets and tight lists on the device like a submission.
@@ -1150,25 +1190,11 @@ extern "C" int vsm_match_pair(vsm_ctx* c, int set0, int set1, const vsm_params* 
     if (kind == SET_F32) {
         const DescSet* A = get_set(c, set0);
         const DescSet* B = get_set(c, set1);
-        const int32_t one[2] = {set0, set1};
-        RunOpts fo;
-        fo.want_dist = dist != nullptr;
-        fo.want_pack = false;
-        bool done = false;
-        if ((rc = f32_pairs_fast(c, one, 1, p, metric, fo, &done)) != VSM_OK) return rc;
-        if (done) {
-            int32_t* cnt = c->h_small.as<int32_t>();
-            HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            const int nm = *cnt;
-            if (nm > cap) return fail(c, VSM_ECAP, "%d matches do not fit a buffer of %d", nm, cap);
-            if (nm > 0) {
-                if (idx0) HIPCHK(c, hipMemcpyAsync(idx0, c->d_slot0.p, sizeof(int32_t) * nm, hipMemcpyDeviceToHost, c->stream));
-                if (idx1) HIPCHK(c, hipMemcpyAsync(idx1, c->d_slot1.p, sizeof(int32_t) * nm, hipMemcpyDeviceToHost, c->stream));
-                if (dist) HIPCHK(c, hipMemcpyAsync(dist, c->d_slotd.p, sizeof(float) * nm, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-            }
-            return nm;
+        const int fast = f32_single_pair_fast(c, A, B, set0, set1, p, metric, idx0, idx1, static_cast<float*>(dist), cap,
+                                              nullptr, nullptr);
+        if (fast != kNotDone) {
+            if (fast > cap) return fail(c, VSM_ECAP, "%d matches do not fit a buffer of %d", fast, cap);
+            return fast;
         }
         std::vector<int32_t> m0(std::max(A->n, 1));
         std::vector<float> b0(std::max(A->n, 1));
@@ -1220,19 +1246,9 @@ extern "C" int vsm_match_pair_dense(vsm_ctx* c, int set0, int set1, const vsm_pa
     const DescSet* A = get_set(c, set0);
     const DescSet* B = get_set(c, set1);
     if (kind == SET_F32) {
-        const int32_t one[2] = {set0, set1};
-        RunOpts fo;
-        fo.want_dense = true;
-        fo.want_pack = false;
-        bool done = false;
-        if ((rc = f32_pairs_fast(c, one, 1, p, metric, fo, &done)) != VSM_OK) return rc;
-        if (!done) return match_pair_f32(c, A, B, p, metric, matches0, matches1, nullptr);
-        int32_t* cnt = c->h_small.as<int32_t>();
-        HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        if (A->n) HIPCHK(c, hipMemcpyAsync(matches0, c->d_dense0.p, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
-        if (B->n) HIPCHK(c, hipMemcpyAsync(matches1, c->d_dense1.p, sizeof(int32_t) * B->n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        return *cnt;
+        const int fast = f32_single_pair_fast(c, A, B, set0, set1, p, metric, nullptr, nullptr, nullptr, 0, matches0, matches1);
+        if (fast != kNotDone) return fast;
+        return match_pair_f32(c, A, B, p, metric, matches0, matches1, nullptr);
     }
     const int32_t pr[2] = {set0, set1};
     Plan pl;
