@@ -188,20 +188,28 @@ def test_scaled_and_clustered_vectors(matcher):
 
 
 def test_survivor_overflow_falls_back(matcher, f32_mode):
-    """40000 copies of one row tie on every query: the survivor lists overflow and the exact kernel takes over."""
+    """600000 copies of one row tie on every query, and every database tile leaves a list entry: the
+    survivor lists overflow and the exact kernel takes over.  A sample of the queries is checked against
+    the oracle."""
     rng = np.random.default_rng(33)
     a = synth.unit_f32(2000, 256, rng)
-    b = np.repeat(synth.unit_f32(1, 256, rng), 40000, axis=0)
+    b = np.repeat(synth.unit_f32(1, 256, rng), 600000, axis=0)
     b[4000] = a[3]
-    for metric in (vsm.METRIC_DOT, vsm.METRIC_L2):
-        _knn_check(matcher, a, b, metric)
-        assert matcher.last_f32_path() == vsm.F32_MFMA_F32
-    # rows sorted so that every next one scores a little higher for query 0: each one is appended and
-    # hundreds stay within the error margin of the best
-    t = np.linspace(0.0, 1.0, 40000, dtype=np.float32)[:, None]
-    b2 = (t * a[0] + (1 - t) * a[1]).astype(np.float32)
-    _knn_check(matcher, a, b2, vsm.METRIC_DOT)
-    assert matcher.last_f32_path() == vsm.F32_MFMA_F32
+    sample = np.r_[0:24, 1990:2000]
+    s0, s1 = matcher.upload_f32(a), matcher.upload_f32(b)
+    try:
+        for metric in (vsm.METRIC_DOT, vsm.METRIC_L2):
+            gi1, gi2, gk1, gk2 = matcher.knn2(s0, s1, metric, want_idx2=True)
+            assert matcher.last_f32_path() == vsm.F32_MFMA_F32
+            oi, ok1, ok2 = orc.knn2_f32(a[sample], b, metric)
+            np.testing.assert_array_equal(gi1[sample], oi)
+            np.testing.assert_array_equal(gk1[sample], ok1)
+            np.testing.assert_array_equal(gk2[sample], ok2)
+            assert gi1[3] == 4000 and gi2[3] == 0
+            assert np.isin(gi1, (0, 4000)).all() and np.isin(gi2, (0, 1)).all()   # ties go to the first row
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)
 
 
 def test_full_survivor_list_drops_stale_entries(matcher, f32_mode):

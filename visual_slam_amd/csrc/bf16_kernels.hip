@@ -124,6 +124,14 @@ struct CoarsePart {   // per (split, query, lane half): coarse top-2 values and 
 // Workgroup = 4 waves; wave w keeps the bf16 operands of kCoarseRB x 32 queries in registers (the
 // accumulator's lane axis), the database streams through LDS in 32 KiB steps (LDS-DMA, double
 // buffered) and every tile read from LDS feeds kCoarseRB MFMA chains.
+// Survivor lists are stored 64 at a time, entry-major: the e-th entries of 64 consecutive lists (the
+// 32 queries x 2 lane halves one wave of the coarse kernel serves) are adjacent, so the part of the
+// list memory that is written and read back is dense.
+__device__ __forceinline__ size_t list_slot(size_t sublist, int e)
+{
+    return (sublist >> 6) * (size_t)(64 * kCoarseCap) + (size_t)e * 64 + (sublist & 63);
+}
+
 constexpr int kCoarseRB = 2;
 constexpr int kCoarseWaves = 4;
 constexpr int kCoarseStripRows = kCoarseWaves * kCoarseRB * 32;  // queries per workgroup
@@ -261,31 +269,31 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
                     tmax = fmaxf(fmaxf(tmax, x0), x1);
                     b2[rb] = fmaxf(b2[rb], u);
                 }
-                if (__ballot(tmax >= thr[rb])) {
-                    // rare: append every row that reaches the threshold as it stood BEFORE this tile
-                    uint2* mylist = lists + (((size_t)split * pr.nA_pad + qidx0 + rb * 32) * 2 + half) * kCoarseCap;
+                thr[rb] = b2[rb] - margin[rb];   // +inf for padded queries, NaN (never reached) before they see two rows
+                if (tmax >= thr[rb]) {
+                    // some of this lane's 16 rows reach the threshold as it stands after this tile (no row
+                    // below it can be among the final survivors): one list entry for the tile, with a bit
+                    // per such row and the largest score as its key.  Padding rows (-inf) get in only while
+                    // thr is -inf; the re-rank drops them.
+                    unsigned rowbits = 0;
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const float x = acc[rb][reg];
-                        if (x >= thr[rb]) {   // padding rows (-inf) get in only while thr is -inf; the re-rank drops them
-                            const int rin = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                            if (cnt[rb] == kCoarseCap) {
-                                // full: the threshold has risen since the early entries went in, and an
-                                // entry below the present threshold can never be a survivor; drop those
-                                int kept = 0;
-                                for (int e = 0; e < kCoarseCap; ++e) {
-                                    const uint2 en = mylist[e];
-                                    if (__uint_as_float(en.y) >= thr[rb]) mylist[kept++] = en;
-                                }
-                                cnt[rb] = kept;
-                            }
-                            if (cnt[rb] < kCoarseCap)
-                                mylist[cnt[rb]] = make_uint2((unsigned)(tile * 32 + rin), __float_as_uint(x));
-                            ++cnt[rb];
+                    for (int reg = 0; reg < 16; ++reg) rowbits |= (acc[rb][reg] >= thr[rb] ? 1u : 0u) << reg;
+                    const size_t mysub = ((size_t)split * pr.nA_pad + qidx0 + rb * 32) * 2 + half;
+                    if (cnt[rb] == kCoarseCap) {
+                        // full: the threshold has risen since the early entries went in, and an entry whose
+                        // key is below the present threshold can never hold a survivor; drop those
+                        int kept = 0;
+                        for (int e = 0; e < kCoarseCap; ++e) {
+                            const uint2 en = lists[list_slot(mysub, e)];
+                            if (__uint_as_float(en.y) >= thr[rb]) lists[list_slot(mysub, kept++)] = en;
                         }
+                        cnt[rb] = kept;
                     }
+                    if (cnt[rb] < kCoarseCap)
+                        lists[list_slot(mysub, cnt[rb])] =
+                            make_uint2(((unsigned)(tile - t0) << 16) | rowbits, __float_as_uint(tmax));
+                    ++cnt[rb];
                 }
-                thr[rb] = b2[rb] - margin[rb];   // +inf for padded queries
             }
         }
     };
@@ -321,6 +329,14 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
 // entries with coarse score >= T2 - margin, and scores those exactly with the k-ascending fmaf chain on
 // the plain row-major f32 copies of the two rows.
 constexpr int kRerankWaves = 4;
+
+// A list entry names up to 16 rows of one database tile: x = (tile - first tile of the split) << 16 |
+// bit per accumulator register, y = the largest coarse score among them.  Register `reg` of lane half
+// `half` holds row (reg & 3) + 8 * (reg >> 2) + 4 * half of the tile.
+__device__ __forceinline__ int entry_row(unsigned x, int reg, int half, int first_tile)
+{
+    return (first_tile + (int)(x >> 16)) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+}
 
 struct Best2 {
     float s1, s2;
@@ -454,19 +470,28 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
             }
             lo = min(lo, 63);
             const int within = e - (__shfl(incl, lo) - __shfl(cnt, lo));
-            bool keep = false;
-            int row = 0;
+            unsigned ex = 0;   // the entry's rows, if it survives the final threshold
             if (e < total) {
-                const uint2 en = lists[sub_index(chunk + lo) * kCoarseCap + within];
-                row = (int)en.x;
-                keep = __uint_as_float(en.y) >= thr && row < pr.nB;
+                const uint2 en = lists[list_slot(sub_index(chunk + lo), within)];
+                if (__uint_as_float(en.y) >= thr) ex = en.x;
             }
-            const unsigned long long mask = __ballot(keep);
-            const int n = __popcll(mask);
-            if (n == 0) continue;
-            if (npending + n > 64) flush();
-            if (keep) rows[npending + __popcll(mask & ((1ull << lane) - 1ull))] = row;
-            npending += n;
+            if (!__ballot((ex & 0xffffu) != 0)) continue;
+            const int sid = chunk + lo;
+            const int first_tile = (sid >> 1) * P.tiles_per_split;
+            // round j queues the j-th named row of every surviving entry (one round, as a rule)
+            unsigned bits = ex & 0xffffu;
+            while (__ballot(bits != 0)) {
+                const int reg = bits ? __ffs(bits) - 1 : 0;
+                const int row = entry_row(ex, reg, sid & 1, first_tile);
+                const bool keep = bits != 0 && row < pr.nB;
+                bits &= bits - 1;
+                const unsigned long long mask = __ballot(keep);
+                const int n = __popcll(mask);
+                if (n == 0) continue;
+                if (npending + n > 64) flush();
+                if (keep) rows[npending + __popcll(mask & ((1ull << lane) - 1ull))] = row;
+                npending += n;
+            }
         }
     }
     flush();
@@ -490,14 +515,14 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
 }
 
 // The same re-rank for submissions of many small problems (few sublists per query, millions of
-// queries): eight queries per wave, one per group of eight lanes, so that a wave's memory round trips
-// (coarse results, list entries, surviving rows) serve eight queries at a time.  Lane `sub` of a group
-// keeps columns [sub * DIMP/8, (sub + 1) * DIMP/8) of its query in registers and reads the same columns
-// of a surviving row; the chain is handed through the group as above.  Results are bit-identical to
-// bf16_rerank_kernel.  Groups whose query lies past the end of the set leave at once; every shuffle below
-// stays inside one group.
+// queries): eight queries per wave.  A group of eight lanes reads the coarse results and the list
+// entries of one query and queues the rows that survive the final threshold; the wave then scores all
+// queued (query, row) pairs at once, one pair per lane: the lane runs the whole k-ascending chain, the
+// query row read from LDS (lanes of one query read the same address), its own database row straight
+// from memory.  Results are bit-identical to bf16_rerank_kernel.
 constexpr int kGroupWaves = 4;
 constexpr int kGroupQueries = kGroupWaves * 8;   // queries per workgroup
+constexpr int kGroupQueue = 32;                  // surviving rows a group collects before the wave scores them
 
 template <int DIMP>
 __global__ __launch_bounds__(kGroupWaves * 64)
@@ -506,37 +531,46 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
                               int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
                               float* __restrict__ k1_all, float* __restrict__ k2_all)
 {
-    constexpr int Q = DIMP / 32;   // float4 pieces of a row per lane
+    constexpr int Q = DIMP / 32;      // float4 pieces of a query row per lane of its group
+    constexpr int NBLK = DIMP / 32;   // 32-column blocks of a row
+    constexpr int AST = DIMP + 4;     // LDS stride of a query row: the eight rows of a wave start in different banks
+    __shared__ int s_queue[kGroupWaves][8][kGroupQueue];
+    __shared__ float s_score[kGroupWaves][8][kGroupQueue];
+    __shared__ __attribute__((aligned(16))) float s_a[kGroupWaves][8][AST];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int sub = lane & 7, gbase = lane & ~7;
+    const int sub = lane & 7, grp = lane >> 3, gbase = lane & ~7;
     const CoarseProblem& P = probs[blockIdx.y];
     const F32Problem pr = P.pr;
-    const int i = ((int)blockIdx.x * kGroupWaves + wave) * 8 + (lane >> 3);
-    if (i >= pr.nA) return;
+    const int i = ((int)blockIdx.x * kGroupWaves + wave) * 8 + grp;
+    const bool live = i < pr.nA;
+    volatile int* queue = s_queue[wave][grp];
+    volatile float* score = s_score[wave][grp];
     const int nsub = P.nsplits * 2;
     const CoarsePart* __restrict__ part = part_all + P.part_off;
     const uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
     auto sub_index = [&](int sid) { return ((size_t)(sid >> 1) * pr.nA_pad + i) * 2 + (sid & 1); };
 
-    float4 a[Q];
-    {
+    if (live) {
         const float4* pa = reinterpret_cast<const float4*>(P.rowsA + (size_t)i * DIMP) + sub * Q;
+        float4* dst = reinterpret_cast<float4*>(&s_a[wave][grp][0]) + sub * Q;
 #pragma unroll
-        for (int u = 0; u < Q; ++u) a[u] = pa[u];
+        for (int u = 0; u < Q; ++u) dst[u] = pa[u];
     }
     const bool l2 = pr.metric == 1;
-    const float na = pr.nrmA[i];
+    const float na = live ? pr.nrmA[i] : 0.0f;
     const float margin = coarse_margin(l2, na, *P.maxnormB_sq);
 
     // final coarse runner-up over all splits and both lane halves
     float T1 = -INFINITY, T2 = -INFINITY;
     int cnt_first = 0;
-    for (int sid = sub; sid < nsub; sid += 8) {
-        const CoarsePart cp = part[sub_index(sid)];
-        T2 = fmaxf(fmaxf(T2, cp.t2), fminf(T1, cp.t1));
-        T1 = fmaxf(T1, cp.t1);
-        if (sid == sub) cnt_first = cp.count;
+    if (live) {
+        for (int sid = sub; sid < nsub; sid += 8) {
+            const CoarsePart cp = part[sub_index(sid)];
+            T2 = fmaxf(fmaxf(T2, cp.t2), fminf(T1, cp.t1));
+            T1 = fmaxf(T1, cp.t1);
+            if (sid == sub) cnt_first = cp.count;
+        }
     }
 #pragma unroll
     for (int m = 1; m < 8; m <<= 1) {
@@ -545,68 +579,112 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
         T1 = fmaxf(T1, o1);
     }
     const float thr = T2 - margin;
+    __syncthreads();   // query rows staged
 
     Best2 best;   // the same in every lane of the group
     best.s1 = -INFINITY; best.s2 = -INFINITY; best.r1 = -1; best.r2 = -1;
-    for (int chunk = 0; chunk < nsub; chunk += 8) {
-        const int sid = chunk + sub;
-        const int cnt = chunk == 0 ? cnt_first : (sid < nsub ? part[sub_index(sid)].count : 0);
-        int incl = cnt;   // inclusive prefix sum of the chunk's list lengths, within the group
+    int nq = 0;   // rows in this group's queue (the same in every lane of the group)
+
+    // whole wave: score every queued (query, row) pair, one per lane, then each group folds its own
+    auto score_all = [&]() {
+        int off[9];
+        off[0] = 0;
 #pragma unroll
-        for (int d = 1; d < 8; d <<= 1) {
-            const int o = __shfl(incl, max(lane - d, gbase));
-            if (sub >= d) incl += o;
-        }
-        const int total = __shfl(incl, gbase + 7);
-        for (int e0 = 0; e0 < total; e0 += 8) {
-            const int e = e0 + sub;
-            int lo = 0;   // sublist of flat entry e: the first lane whose inclusive prefix exceeds e
+        for (int j = 0; j < 8; ++j) off[j + 1] = off[j] + __shfl(nq, j * 8);
+        const int total = off[8];
+        for (int t0 = 0; t0 < total; t0 += 64) {
+            const int t = t0 + lane;
+            int g = 0;
 #pragma unroll
-            for (int step = 4; step >= 1; step >>= 1) {
-                const int probe = __shfl(incl, gbase + lo + step - 1);
-                if (probe <= e) lo += step;
-            }
-            lo = min(lo, 7);
-            const int within = e - (__shfl(incl, gbase + lo) - __shfl(cnt, gbase + lo));
-            bool keep = false;
-            int row = 0;
-            if (e < total) {
-                const uint2 en = lists[sub_index(chunk + lo) * kCoarseCap + within];
-                row = (int)en.x;
-                keep = __uint_as_float(en.y) >= thr && row < pr.nB;
-            }
-            unsigned m = (unsigned)(__ballot(keep) >> gbase) & 0xffu;   // this group's survivors
-            while (m) {
-                const int bit = __ffs(m) - 1;
-                m &= m - 1;
-                const int r = __shfl(row, gbase + bit);
-                const float4* pb = reinterpret_cast<const float4*>(P.rowsB + (size_t)r * DIMP) + sub * Q;
-                float4 b[Q];
+            for (int j = 1; j < 8; ++j) g += off[j] <= t ? 1 : 0;
+            const bool valid = t < total;
+            int og = 0;   // off[g] without indexing registers by a lane-varying value
 #pragma unroll
-                for (int u = 0; u < Q; ++u) b[u] = pb[u];
-                const float nbr = pr.nrmB[r];
+            for (int j = 1; j < 8; ++j) og = g >= j ? off[j] : og;
+            const int qi = valid ? t - og : 0;
+            const int r = valid ? reinterpret_cast<volatile int*>(&s_queue[wave][g][0])[qi] : -1;
+            if (r >= 0) {
+                const float4* pb = reinterpret_cast<const float4*>(P.rowsB + (size_t)r * DIMP);
+                const float4* pa = reinterpret_cast<const float4*>(&s_a[wave][g][0]);
+                float4 b[8], bn[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) b[u] = pb[u];
                 float d = 0.0f;
+#pragma unroll 1
+                for (int blk = 0; blk < NBLK; ++blk) {
+                    if (blk + 1 < NBLK) {
 #pragma unroll
-                for (int stage = 0; stage < 8; ++stage) {
-                    if (sub == stage) {
-#pragma unroll
-                        for (int u = 0; u < Q; ++u) {
-                            d = fmaf(b[u].x, a[u].x, d);
-                            d = fmaf(b[u].y, a[u].y, d);
-                            d = fmaf(b[u].z, a[u].z, d);
-                            d = fmaf(b[u].w, a[u].w, d);
-                        }
+                        for (int u = 0; u < 8; ++u) bn[u] = pb[(blk + 1) * 8 + u];
                     }
-                    const float handed = __shfl(d, gbase + stage);
-                    if (sub == stage + 1) d = handed;
-                    if (stage == 7) d = handed;   // the finished chain, in every lane of the group
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float4 av = pa[blk * 8 + u];
+                        d = fmaf(b[u].x, av.x, d);
+                        d = fmaf(b[u].y, av.y, d);
+                        d = fmaf(b[u].z, av.z, d);
+                        d = fmaf(b[u].w, av.w, d);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) b[u] = bn[u];
                 }
-                const float sc = l2 ? fmaf(2.0f, d, -nbr) : d;
-                if (sc > -INFINITY) best2_insert(best, sc, r);
+                const float sc = l2 ? fmaf(2.0f, d, -pr.nrmB[r]) : d;
+                reinterpret_cast<volatile float*>(&s_score[wave][g][0])[qi] = sc;
+            } else if (valid) {
+                reinterpret_cast<volatile float*>(&s_score[wave][g][0])[qi] = -INFINITY;   // a padding row of the last tile
+            }
+        }
+        for (int q = 0; q < nq; ++q) {
+            const float sc = score[q];
+            if (sc > -INFINITY) best2_insert(best, sc, queue[q]);
+        }
+        nq = 0;
+    };
+
+    for (int sid = 0; sid < nsub; ++sid) {
+        // list length: lane (sid & 7) of the group read it above when sid < 8
+        int cnt = __shfl(cnt_first, gbase + (sid & 7));
+        if (sid >= 8) cnt = live ? part[sub_index(sid)].count : 0;
+        const size_t mysub = sub_index(sid);
+        const int first_tile = (sid >> 1) * P.tiles_per_split;
+        for (int e0 = 0; __any(e0 < cnt); e0 += 32) {
+            unsigned ex[4];   // four entries per lane in flight
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + 8 * k + sub;
+                ex[k] = 0;
+                if (e < cnt) {
+                    const uint2 en = lists[list_slot(mysub, e)];
+                    if (__uint_as_float(en.y) >= thr) ex[k] = en.x;
+                }
+            }
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                unsigned m = (unsigned)(__ballot((ex[0] & 0xffffu) != 0) >> gbase) & 0xffu;   // this group's survivors
+                while (__any(m != 0)) {
+                    if (__any(nq + 16 > kGroupQueue)) score_all();
+                    if (m) {
+                        const int src = __ffs(m) - 1;
+                        m &= m - 1;
+                        const unsigned x = __shfl(ex[0], gbase + src);
+                        const unsigned bits = x & 0xffffu;
+                        // lane `sub` places the rows of registers sub and sub + 8
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int reg = sub + 8 * h;
+                            if ((bits >> reg) & 1u) {
+                                const int r = entry_row(x, reg, sid & 1, first_tile);
+                                queue[nq + __popc(bits & ((1u << reg) - 1u))] = r < pr.nB ? r : -1;
+                            }
+                        }
+                        nq += __popc(bits);
+                    }
+                }
+                ex[0] = ex[1]; ex[1] = ex[2]; ex[2] = ex[3]; ex[3] = 0;
             }
         }
     }
-    if (sub == 0) {
+    score_all();
+    if (live && sub == 0) {
         const int64_t o = P.out_off + i;
         j1_all[o] = best.r1;
         j2_all[o] = best.r2;
@@ -631,6 +709,7 @@ CoarseTotals plan_coarse(CoarseProblem* probs, int n, int target_wgs)
         p.nstrips = p.pr.nA_pad / kCoarseStripRows;
         int tps = (ntiles + want - 1) / want;
         tps = std::max(8, (tps + 7) & ~7);            // whole LDS steps at every dimension
+        tps = std::min(tps, 65536);                   // a list entry has 16 bits for the tile within its split
         p.tiles_per_split = tps;
         p.nsplits = std::max(1, (ntiles + tps - 1) / tps);
         p.blk0 = t.coarse_blocks;
