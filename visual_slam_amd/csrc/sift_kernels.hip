@@ -300,6 +300,8 @@ void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
 // operand-order layout: kVerifyRB blocks of 32 per wave, sharing every streamed operand read);
 // streamed set = all of image 0.  Per candidate: the nearest image-0 row.
 constexpr int kVerifyWaves = 4;
+constexpr int kVerifyGrid = 1024;      // workgroups of the verify pass
+constexpr int kVerifyMaxSplit = 64;    // most ranges of image-0 steps a block of candidates is cut into
 constexpr int kVerifyRB = kVerifyBlock / (32 * kVerifyWaves);
 
 __global__ __launch_bounds__(kVerifyWaves * 64, 2)
@@ -313,11 +315,17 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
     const int lane5 = lane & 31;
     const int half = lane >> 5;
     // The item list is built on the device (only blocks that hold candidates); a fixed grid walks it
-    // round-robin, so every workgroup leaves after at most ceil(total / gridDim.x) items.
-    const int total = *nvitems;
-    for (int w = blockIdx.x; w < total; w += gridDim.x) {
-    const SiftItem it = vitems[w];
+    // round-robin, so every workgroup leaves after at most ceil(work / gridDim.x) items.  When the
+    // list is short (one large pair), every block is also cut into `nsplit` ranges of image-0 steps,
+    // and the ranges meet in a 64-bit atomic minimum of (distance, row).
+    const int total = nvitems[0], nsplit = nvitems[1];
+    for (int w = blockIdx.x; w < total * nsplit; w += gridDim.x) {
+    const SiftItem it = vitems[w / nsplit];
+    const int part = w % nsplit;
     const SiftPair pw = pairs[it.pair];
+    const int allsteps = pw.nA_pad / kStepRows;
+    const int st0 = (int)((long long)allsteps * part / nsplit), st1 = (int)((long long)allsteps * (part + 1) / nsplit);
+    if (st0 == st1) continue;
     const int ncand = cand.count[it.pair];
     const int cbase = it.strip * kVerifyBlock;
 
@@ -332,7 +340,6 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
         for (int s = 0; s < 4; ++s) pf[rb][s] = *reinterpret_cast<const v4i*>(src + s * 1024);
     }
 
-    const int nsteps = pw.nA_pad / kStepRows;
     const int8_t* Asrc = pw.fragA + wave * (kLdsTile / kVerifyWaves) + lane * 16;
     const int32_t* Nsrc = pw.nrmA + (wave & 3) * 64 + lane;
 
@@ -340,12 +347,12 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
 #pragma unroll
     for (int rb = 0; rb < kVerifyRB; ++rb) { bestd[rb] = kDistPad; bestrow[rb] = INT32_MAX; }
 
-    stage_step<kVerifyWaves>(smem, 0, Asrc, Nsrc, wave);
+    stage_step<kVerifyWaves>(smem, 0, Asrc + (size_t)st0 * kLdsTile, Nsrc + st0 * kStepRows, wave);
     __syncthreads();
 
-    for (int st = 0; st < nsteps; ++st) {
-        const int cur = st & 1;
-        if (st + 1 < nsteps)
+    for (int st = st0; st < st1; ++st) {
+        const int cur = (st - st0) & 1;
+        if (st + 1 < st1)
             stage_step<kVerifyWaves>(smem, cur ^ 1, Asrc + (size_t)(st + 1) * kLdsTile, Nsrc + (st + 1) * kStepRows, wave);
         const char* At = smem + cur * kLdsTile + lane * 16;
         const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm);
@@ -399,12 +406,15 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
             bestd[rb] = od;
             bestrow[rb] = orow;
         }
-        if (half == 0 && ci[rb] < ncand) cand.vrow[pw.out0_off + ci[rb]] = bestrow[rb];
+        if (half == 0 && ci[rb] < ncand)
+            atomicMin(&cand.vbest[pw.out0_off + ci[rb]],
+                      ((unsigned long long)((unsigned)bestd[rb] ^ 0x80000000u) << 32) | (unsigned)bestrow[rb]);   // sign bit flipped: the distances are relative (the candidate's own norm is left out) and may be negative
     }
     }   // next work item (the last step's barrier separates it from this one's LDS reads)
 }
 
-// counts[pair] -> compact list of (pair, block of kVerifyBlock candidates), total in *nvitems
+// counts[pair] -> compact list of (pair, block of kVerifyBlock candidates); nvitems[0] = its length,
+// nvitems[1] = ranges of image-0 steps every block is cut into (so that a short list still fills the grid)
 __global__ __launch_bounds__(1024)
 void sift_verify_plan_kernel(const int32_t* __restrict__ counts, int npairs, SiftItem* __restrict__ vitems,
                              int* __restrict__ nvitems)
@@ -435,7 +445,11 @@ void sift_verify_plan_kernel(const int32_t* __restrict__ counts, int npairs, Sif
         if (tid == 0) carry_s += tot;
         __syncthreads();
     }
-    if (tid == 0) *nvitems = carry_s;
+    if (tid == 0) {
+        const int total = carry_s;
+        nvitems[0] = total;
+        nvitems[1] = total > 0 && total * 2 <= kVerifyGrid ? min(kVerifyGrid / total, kVerifyMaxSplit) : 1;
+    }
 }
 
 
@@ -450,7 +464,7 @@ void launch_sift_verify(const SiftPair* pairs, int npairs, SiftItem* vitems, int
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsStream);
         attr_set = true;
     }
-    hipLaunchKernelGGL(sift_verify_kernel, dim3(std::min(max_vitems, 1024)), dim3(kVerifyWaves * 64), kLdsStream, s,
+    hipLaunchKernelGGL(sift_verify_kernel, dim3(kVerifyGrid), dim3(kVerifyWaves * 64), kLdsStream, s,
                        pairs, vitems, nvitems, cand, -512);
 }
 
@@ -468,41 +482,68 @@ void sift_select_kernel(const SiftPair* __restrict__ pairs,
     if (tid == 0) base_s = 0;
     __syncthreads();
 
-    for (int i0 = 0; i0 < pw.nA; i0 += 1024) {
-        const int i = i0 + tid;
-        int j1 = -1, d1 = INT32_MAX, d2 = INT32_MAX;
-        bool ok = false;
-        if (i < pw.nA) {
+    // eight consecutive rows per thread and round: few rounds (and barriers) even for a very large set,
+    // and the candidates still come out in ascending row order
+    constexpr int R = 8;
+    for (int i0 = 0; i0 < pw.nA; i0 += 1024 * R) {
+        const int ib = i0 + tid * R;   // nA_pad is a multiple of 512 and so is row_off: 32-byte aligned
+        int j1[R], d1[R], d2[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { j1[r] = -1; d1[r] = INT32_MAX; d2[r] = INT32_MAX; }
+        if (ib < pw.nA) {
             // merge chunks (ascending column ranges: a strict compare keeps the lowest column)
             for (int c = 0; c < pw.nchunks; ++c) {
-                const size_t o = pw.row_off + (size_t)c * pw.nA_pad + i;
-                const int e1 = rr_d1[o], ej = rr_j1[o], e2 = rr_d2[o];
-                if (e1 < d1) {
-                    d2 = min(d1, e2);
-                    d1 = e1;
-                    j1 = ej;
-                } else {
-                    d2 = min(d2, e1);
+                const size_t o = pw.row_off + (size_t)c * pw.nA_pad + ib;
+                int e1[R], ej[R], e2[R];
+#pragma unroll
+                for (int q = 0; q < R / 4; ++q) {
+                    const int4 v1 = *reinterpret_cast<const int4*>(rr_d1 + o + 4 * q);
+                    const int4 vj = *reinterpret_cast<const int4*>(rr_j1 + o + 4 * q);
+                    const int4 v2 = *reinterpret_cast<const int4*>(rr_d2 + o + 4 * q);
+                    e1[4 * q] = v1.x; e1[4 * q + 1] = v1.y; e1[4 * q + 2] = v1.z; e1[4 * q + 3] = v1.w;
+                    ej[4 * q] = vj.x; ej[4 * q + 1] = vj.y; ej[4 * q + 2] = vj.z; ej[4 * q + 3] = vj.w;
+                    e2[4 * q] = v2.x; e2[4 * q + 1] = v2.y; e2[4 * q + 2] = v2.z; e2[4 * q + 3] = v2.w;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (e1[r] < d1[r]) {
+                        d2[r] = min(d1[r], e2[r]);
+                        d1[r] = e1[r];
+                        j1[r] = ej[r];
+                    } else {
+                        d2[r] = min(d2[r], e1[r]);
+                    }
                 }
             }
-            if (j1 >= pw.nB) j1 = -1;
-            ok = j1 >= 0;
-            if (out.knn_j1) {
-                out.knn_j1[pw.out0_off + i] = j1;
-                out.knn_d1[pw.out0_off + i] = d1;
-                out.knn_d2[pw.out0_off + i] = d2;
-            }
-            if (ok && rule.max_dist >= 0 && (long long)d1 > rule.max_dist) ok = false;
-            if (ok && rule.num2 > 0 && d2 != INT32_MAX) {
-                if (!((long long)d1 * rule.den2 < (long long)d2 * rule.num2)) ok = false;
-            }
         }
-        const int slot = block_compact_slot(ok, wsum, &base_s);
-        if (ok) {
-            const size_t o = pw.out0_off + slot;
-            cand.i0[o] = i;
-            cand.j1[o] = j1;
-            cand.d1[o] = d1;
+        unsigned okbits = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = ib + r;
+            if (i >= pw.nA) continue;
+            if (j1[r] >= pw.nB) j1[r] = -1;
+            bool ok = j1[r] >= 0;
+            if (out.knn_j1) {
+                out.knn_j1[pw.out0_off + i] = j1[r];
+                out.knn_d1[pw.out0_off + i] = d1[r];
+                out.knn_d2[pw.out0_off + i] = d2[r];
+            }
+            if (ok && rule.max_dist >= 0 && (long long)d1[r] > rule.max_dist) ok = false;
+            if (ok && rule.num2 > 0 && d2[r] != INT32_MAX) {
+                if (!((long long)d1[r] * rule.den2 < (long long)d2[r] * rule.num2)) ok = false;
+            }
+            okbits |= (ok ? 1u : 0u) << r;
+        }
+        int slot = block_compact_range(__popc(okbits), wsum, &base_s);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if ((okbits >> r) & 1u) {
+                const size_t o = pw.out0_off + slot++;
+                cand.i0[o] = ib + r;
+                cand.j1[o] = j1[r];
+                cand.d1[o] = d1[r];
+                cand.vbest[o] = ~0ull;
+            }
         }
     }
     __syncthreads();
@@ -542,7 +583,7 @@ void sift_confirm_kernel(const SiftPair* __restrict__ pairs, SiftCandidates cand
             i = cand.i0[o];
             j = cand.j1[o];
             d = cand.d1[o];
-            ok = !mutual || cand.vrow[o] == i;
+            ok = !mutual || (int)(unsigned)(cand.vbest[o] & 0xffffffffull) == i;
         }
         const int slot = block_compact_slot(ok, wsum, &base_s);
         if (ok) {

@@ -234,7 +234,7 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     HIPCHK(c, c->d_rr1.ensure(rows * 4));
     HIPCHK(c, c->d_rrj.ensure(rows * 4));
     HIPCHK(c, c->d_rr2.ensure(rows * 4));
-    HIPCHK(c, c->d_cand.ensure(out0 * 16 + sizeof(int32_t) * std::max(npairs, 1)));
+    HIPCHK(c, c->d_cand.ensure(out0 * 20 + sizeof(int32_t) * std::max(npairs, 1)));
     HIPCHK(c, c->d_slot0.ensure(out0 * 4));
     HIPCHK(c, c->d_slot1.ensure(out0 * 4));
     if (o.want_dist) HIPCHK(c, c->d_slotd.ensure(out0 * 4));
@@ -275,11 +275,11 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     }
     if (npairs) {
         SiftCandidates cand{};
-        cand.i0 = c->d_cand.as<int32_t>();
+        cand.vbest = c->d_cand.as<unsigned long long>();
+        cand.i0 = reinterpret_cast<int32_t*>(cand.vbest + out0);
         cand.j1 = cand.i0 + out0;
         cand.d1 = cand.j1 + out0;
-        cand.vrow = cand.d1 + out0;
-        cand.count = cand.vrow + out0;
+        cand.count = cand.d1 + out0;
         SiftOutputs out{};
         out.slot_i0 = c->d_slot0.as<int32_t>();
         out.slot_i1 = c->d_slot1.as<int32_t>();

@@ -60,7 +60,9 @@ struct SiftCandidates {
     int32_t* j1;
     int32_t* d1;
     int32_t* count;   // [npairs]
-    int32_t* vrow;    // nearest image-0 row of column j1 (filled by the verify pass)
+    // nearest image-0 row of column j1 as (distance with its sign bit flipped << 32 | row): set to all ones by the select pass,
+    // lowered by the verify pass with an atomic minimum (lowest row among equal distances)
+    unsigned long long* vbest;
 };
 
 struct SiftOutputs {
@@ -98,6 +100,31 @@ __device__ __forceinline__ int block_compact_slot(bool flag, int* wsum, int* bas
     if (tid == 0) *base_s = base + tot;
     __syncthreads();
     return base + woff + before;
+}
+
+// The same for threads that flag `n` consecutive outputs each: returns the first of this thread's slots.
+__device__ __forceinline__ int block_compact_range(int n, int* wsum, int* base_s)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+        const int c = wsum[w];
+        if (w < wave) woff += c;
+        tot += c;
+    }
+    const int base = *base_s;
+    __syncthreads();
+    if (tid == 0) *base_s = base + tot;
+    __syncthreads();
+    return base + woff + incl - n;
 }
 
 // ---- float path: accept tests of a submission of pairs ---------------------------------
