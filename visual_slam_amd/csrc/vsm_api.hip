@@ -377,7 +377,7 @@ extern "C" vsm_ctx* vsm_create(int device)
         (e = hipEventCreateWithFlags(&c->slots[0].packed, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->slots[1].packed, hipEventDisableTiming)) != hipSuccess) {
         fail(nullptr, VSM_ENODEV, "stream/event creation: %s", hipGetErrorString(e));
-        delete c;
+        vsm_destroy(c);   // releases whatever was created
         return nullptr;
     }
     return c;
@@ -466,6 +466,8 @@ static int upload_u8_common(vsm_ctx* c, const void* src, int n, bool src_on_devi
 {
     if (!c) return VSM_EINVAL;
     if (n < 0 || (n > 0 && !src)) return fail(c, VSM_EINVAL, "bad descriptor buffer (n=%d)", n);
+    // work items name blocks of kVerifyBlock rows in 16 bits
+    if (n > 32767 * kVerifyBlock) return fail(c, VSM_EINVAL, "a u8 set holds at most %d rows (got %d)", 32767 * kVerifyBlock, n);
     HIPCHK(c, hipSetDevice(c->device));
     DescSet s;
     s.kind = SET_U8;
@@ -898,8 +900,8 @@ int f32_pairs_fast(vsm_ctx* c, const int32_t* pairs, int npairs, const vsm_param
 
 // One float pair, lists or dense forms straight into the caller's buffers with a single wait: the
 // coarse / re-rank / accept kernels, the overflow flag and the result copies are queued together, and
-// the flag is looked at after the one synchronisation.  Returns the match count, or VSM_EUNSUPPORTED - 1000
-// ("not done") when the context is in f32-only mode or a survivor list overflowed.
+// the flag is looked at after the one synchronisation.  Returns the match count, a VSM_E* code, or
+// kNotDone when the context is in f32-only mode or a survivor list overflowed.
 constexpr int kNotDone = -1000;
 int f32_single_pair_fast(vsm_ctx* c, const DescSet* A, const DescSet* B, int set0, int set1, const vsm_params* p,
                          int metric, int32_t* idx0, int32_t* idx1, float* dist, int cap, int32_t* dense0,
@@ -989,6 +991,7 @@ extern "C" long long vsm_match_pairs_device(vsm_ctx* c, const int32_t* pairs, in
     if (npairs < 0 || (npairs > 0 && !pairs)) return fail(c, VSM_EINVAL, "bad pair list");
     int rc = check_params(c, p);
     if (rc) return rc;
+    if (c->inflight) return fail(c, VSM_EINVAL, "collect the submissions in flight first");   // it would reuse their result slot
     HIPCHK(c, hipSetDevice(c->device));
     const DescSet* first = npairs > 0 ? get_set(c, pairs[0]) : nullptr;
     const bool float_sets = first && first->kind == SET_F32;
