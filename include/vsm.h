@@ -156,6 +156,35 @@ int vsm_merge_top2_device(vsm_ctx* ctx, const void* packed_dev, const int64_t* b
 int vsm_nearest_embed(vsm_ctx* ctx, const float* x, int batch, int dim, int npts,
                       const float* emb, int k, int64_t* argmin, float* result);
 
+/* ---- geometric verification of putative matches ----------------------------------- */
+/* The step that follows matching in the workflow the reference feeds: a fundamental matrix and the
+ * inlier matches per image pair, the content of a match record's TwoViewGeometry and inlier lists
+ * (MatchFile.h:68-161, WriteFMatch / WriteIMatch MatchFile.cpp:596-748); the reference's Python side
+ * gets it from cv2.findEssentialMat(..., RANSAC) (models/utils.py:288-312).  The reference holds no
+ * estimator of its own; this one is RANSAC over the normalised eight-point solve with Sampson-distance
+ * inliers, deterministic for a given seed (samples come from a counter-based generator keyed by seed,
+ * pair position in the call and sample number).  x1^T F x0 = 0 for a keypoint x0 of the pair's first
+ * image and its match x1 in the second; F has unit Frobenius norm and rank 2. */
+typedef struct vsm_geom_params {
+    float max_sampson;   /* inlier threshold on the Sampson distance, in pixels (> 0) */
+    int hypotheses;      /* samples per pair; 0 = 256 */
+    unsigned seed;
+    int min_inliers;     /* a pair with fewer inliers reports none (NF = 0, F = 0) */
+} vsm_geom_params;
+/* Keypoint locations of one image, n x (x, y) floats (the first two columns of a .sift location
+ * record, FeaturePoints.cpp:388-446).  Returns a set id (released with vsm_release_set). */
+int vsm_upload_xy(vsm_ctx* ctx, const float* xy, int n);
+/* xy_pairs[npairs][2]: keypoint sets of each pair's two images.  The putative matches come as
+ * offsets[npairs + 1] / idx0 / idx1 (the layout vsm_match_pairs returns), or, with all three NULL, are
+ * the lists of the last collected submission of npairs pairs, read where they lie on the device.
+ * Out: F[npairs][9] (row-major, may be NULL), nf[npairs] (may be NULL), in_offsets[npairs + 1] and
+ * the inlier matches of all pairs in in_idx0 / in_idx1 (feature indices, in match order).
+ * Returns the total number of inlier matches, or VSM_ECAP with in_offsets filled. */
+long long vsm_verify_matches(vsm_ctx* ctx, const int32_t* xy_pairs, int npairs, const int64_t* offsets,
+                             const int32_t* idx0, const int32_t* idx1, const vsm_geom_params* g,
+                             float* F, int32_t* nf, int64_t* in_offsets, int32_t* in_idx0,
+                             int32_t* in_idx1, long long cap);
+
 /* ---- measurement ----------------------------------------------------------------- */
 /* With timing on, the distance kernel of each submission is bracketed by HIP events on
  * the context's stream; vsm_last_kernel_ms returns the last bracket (synchronises). */
@@ -222,6 +251,19 @@ int vsm_mat_get_pmatch_r(const char* image, const char* other, int fc_other,
                          int32_t* row0, int32_t* row1, int cap);
 /* MatchFile::GetMatchCount (MatchFile.cpp:938-958). Returns 1/0. */
 int vsm_mat_get_match_count(const char* image, const char* other, int* nm, int* nf);
+
+/* MatchFile::WriteFMatch (MatchFile.cpp:596-605 -> WriteIMatch :643-748): geometry (NF, F) and the
+ * inlier index lists into the record of the pair in both images' files (F transposed and the rows
+ * swapped in the second, as SetGeometryR and :735-746 do).  The pair's putative record must exist
+ * (vsm_mat_write_pmatch).  Returns 1, 0 if a file has no such record, or a negative code. */
+int vsm_mat_write_fmatch(const char* image1, const char* image2, int nf, const int32_t* idx1,
+                         const int32_t* idx2, const float* F);
+/* MatchFile::GetIMatch / GetIMatchR (MatchFile.cpp:961-1084): F[9], *nf and up to cap inlier pairs;
+ * returns NM of the record (0 when absent or rejected by the reference's checks). */
+int vsm_mat_get_imatch(const char* image, const char* other, int fc_other, float* F, int* nf,
+                       int32_t* row0, int32_t* row1, int cap);
+int vsm_mat_get_imatch_r(const char* image, const char* other, int fc_other, float* F, int* nf,
+                         int32_t* row0, int32_t* row1, int cap);
 
 #ifdef __cplusplus
 }

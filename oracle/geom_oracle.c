@@ -1,0 +1,236 @@
+/* CPU checker for the geometric verification of putative matches.  TEST INFRASTRUCTURE ONLY: nothing
+ * in the product library links, loads or calls this file.
+ *
+ * The reference has no estimator of its own for this step: its C++ side stores what an estimator
+ * returns (TwoViewGeometry and the inlier lists of a match record, MatchFile.h:68-161,
+ * MatchFile.cpp:596-748) and its Python side calls OpenCV, which is not installed here
+ * (cv2.findEssentialMat with RANSAC, models/utils.py:288-312).  PARITY UNPINNED: no fixture or output
+ * of the reference covers the estimate.  What this file pins is the library's own stated algorithm,
+ * restated in scalar C with plain arrays, operation for operation:
+ *   sample h of the pair at position p of a call: eight distinct matches from splitmix64 counters;
+ *   Hartley normalisation, 8 x 9 system of x1^T F x0 = 0, Gaussian elimination with complete
+ *   pivoting, free unknown 1, unit norm, de-normalisation, unit Frobenius norm (double);
+ *   inliers by e^2 < t^2 (a0^2 + a1^2 + b0^2 + b1^2) in float; most inliers wins, lowest h on ties;
+ *   the winner projected to rank 2 (Jacobi on F^T F), inliers re-scored, listed in match order. */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+static int inlier(const float* F, const float* p, float t2)
+{
+    const float a0 = (F[0] * p[0] + F[1] * p[1]) + F[2];
+    const float a1 = (F[3] * p[0] + F[4] * p[1]) + F[5];
+    const float a2 = (F[6] * p[0] + F[7] * p[1]) + F[8];
+    const float b0 = (F[0] * p[2] + F[3] * p[3]) + F[6];
+    const float b1 = (F[1] * p[2] + F[4] * p[3]) + F[7];
+    const float e = (p[2] * a0 + p[3] * a1) + a2;
+    const float den = ((a0 * a0 + a1 * a1) + b0 * b0) + b1 * b1;
+    return e * e < t2 * den;
+}
+
+/* eight matches (x0, y0, x1, y1) -> F (float, unit Frobenius norm); 0 if the sample is degenerate */
+static int eight_point(const float pt[8][4], float* Fout)
+{
+    double c[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 8; ++k)
+        for (int d = 0; d < 4; ++d) c[d] += (double)pt[k][d];
+    for (int d = 0; d < 4; ++d) c[d] /= 8.0;
+    double md0 = 0, md1 = 0;
+    for (int k = 0; k < 8; ++k) {
+        const double dx0 = (double)pt[k][0] - c[0], dy0 = (double)pt[k][1] - c[1];
+        const double dx1 = (double)pt[k][2] - c[2], dy1 = (double)pt[k][3] - c[3];
+        md0 += sqrt(dx0 * dx0 + dy0 * dy0);
+        md1 += sqrt(dx1 * dx1 + dy1 * dy1);
+    }
+    md0 /= 8.0;
+    md1 /= 8.0;
+    if (!(md0 > 0.0) || !(md1 > 0.0)) return 0;
+    const double s0 = 1.4142135623730951 / md0, s1 = 1.4142135623730951 / md1;
+    double A[8][9];
+    for (int k = 0; k < 8; ++k) {
+        const double x0 = ((double)pt[k][0] - c[0]) * s0, y0 = ((double)pt[k][1] - c[1]) * s0;
+        const double x1 = ((double)pt[k][2] - c[2]) * s1, y1 = ((double)pt[k][3] - c[3]) * s1;
+        A[k][0] = x1 * x0; A[k][1] = x1 * y0; A[k][2] = x1;
+        A[k][3] = y1 * x0; A[k][4] = y1 * y0; A[k][5] = y1;
+        A[k][6] = x0;      A[k][7] = y0;      A[k][8] = 1.0;
+    }
+    int perm[9];
+    for (int j = 0; j < 9; ++j) perm[j] = j;
+    for (int k = 0; k < 8; ++k) {
+        double best = 0.0;
+        int pr = k, pc = k;
+        for (int r = k; r < 8; ++r)
+            for (int cc = k; cc < 9; ++cc) {
+                const double v = fabs(A[r][cc]);
+                if (v > best) { best = v; pr = r; pc = cc; }
+            }
+        if (!(best > 0.0)) return 0;
+        if (pr != k)
+            for (int cc = 0; cc < 9; ++cc) { const double t = A[k][cc]; A[k][cc] = A[pr][cc]; A[pr][cc] = t; }
+        if (pc != k) {
+            for (int r = 0; r < 8; ++r) { const double t = A[r][k]; A[r][k] = A[r][pc]; A[r][pc] = t; }
+            const int t = perm[k]; perm[k] = perm[pc]; perm[pc] = t;
+        }
+        const double piv = A[k][k];
+        for (int r = k + 1; r < 8; ++r) {
+            const double f = A[r][k] / piv;
+            for (int cc = k + 1; cc < 9; ++cc) A[r][cc] -= f * A[k][cc];
+        }
+    }
+    double x[9];
+    x[8] = 1.0;
+    for (int k = 7; k >= 0; --k) {
+        double s = 0.0;
+        for (int cc = k + 1; cc < 9; ++cc) s += A[k][cc] * x[cc];
+        x[k] = -s / A[k][k];
+    }
+    double f[9], nn = 0.0;
+    for (int j = 0; j < 9; ++j) f[perm[j]] = x[j];
+    for (int j = 0; j < 9; ++j) nn += f[j] * f[j];
+    nn = sqrt(nn);
+    if (!(nn > 0.0)) return 0;
+    for (int j = 0; j < 9; ++j) f[j] /= nn;
+    double M[9], G[9];
+    for (int i = 0; i < 3; ++i) {
+        M[3 * i + 0] = f[3 * i + 0] * s0;
+        M[3 * i + 1] = f[3 * i + 1] * s0;
+        M[3 * i + 2] = f[3 * i + 2] - (M[3 * i + 0] * c[0] + M[3 * i + 1] * c[1]);
+    }
+    for (int j = 0; j < 3; ++j) {
+        G[j] = s1 * M[j];
+        G[3 + j] = s1 * M[3 + j];
+        G[6 + j] = M[6 + j] - (G[j] * c[2] + G[3 + j] * c[3]);
+    }
+    double fn = 0.0;
+    for (int j = 0; j < 9; ++j) fn += G[j] * G[j];
+    fn = sqrt(fn);
+    if (!(fn > 0.0) || !(fn < 1e300)) return 0;
+    for (int j = 0; j < 9; ++j) Fout[j] = (float)(G[j] / fn);
+    return 1;
+}
+
+static void rank2(const float* Fin, float* Fout)
+{
+    double F[9], S[9], V[9];
+    for (int j = 0; j < 9; ++j) F[j] = (double)Fin[j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            S[3 * i + j] = (F[i] * F[j] + F[3 + i] * F[3 + j]) + F[6 + i] * F[6 + j];
+            V[3 * i + j] = i == j ? 1.0 : 0.0;
+        }
+    static const int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
+    for (int sweep = 0; sweep < 12; ++sweep)
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = P[pq], q = Q[pq];
+            const double apq = S[3 * p + q];
+            if (apq == 0.0) continue;
+            const double theta = (S[3 * q + q] - S[3 * p + p]) / (2.0 * apq);
+            const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+            for (int k = 0; k < 3; ++k) {
+                const double a = S[3 * k + p], b = S[3 * k + q];
+                S[3 * k + p] = c * a - s * b;
+                S[3 * k + q] = s * a + c * b;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double a = S[3 * p + k], b = S[3 * q + k];
+                S[3 * p + k] = c * a - s * b;
+                S[3 * q + k] = s * a + c * b;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double a = V[3 * k + p], b = V[3 * k + q];
+                V[3 * k + p] = c * a - s * b;
+                V[3 * k + q] = s * a + c * b;
+            }
+        }
+    int im = 0;
+    if (S[4] < S[0]) im = 1;
+    if (S[8] < S[3 * im + im]) im = 2;
+    const double v0 = V[im], v1 = V[3 + im], v2 = V[6 + im];
+    double G[9], fn = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        const double fv = (F[3 * i] * v0 + F[3 * i + 1] * v1) + F[3 * i + 2] * v2;
+        G[3 * i + 0] = F[3 * i + 0] - fv * v0;
+        G[3 * i + 1] = F[3 * i + 1] - fv * v1;
+        G[3 * i + 2] = F[3 * i + 2] - fv * v2;
+    }
+    for (int j = 0; j < 9; ++j) fn += G[j] * G[j];
+    fn = sqrt(fn);
+    for (int j = 0; j < 9; ++j) Fout[j] = fn > 0.0 ? (float)(G[j] / fn) : 0.0f;
+}
+
+/* One pair.  xy0 / xy1: keypoints (n0 / n1 rows of x, y); idx0 / idx1: n putative matches.
+ * pair_pos: the pair's position in the call that is being checked (part of the sampling key).
+ * Out: F[9] (zeros if the pair reports nothing), in0 / in1 (capacity n).  Returns NF. */
+int oracle_geom_pair(const float* xy0, int n0, const float* xy1, int n1, const int32_t* idx0, const int32_t* idx1, int n,
+                     float max_sampson, int hypotheses, unsigned seed, unsigned pair_pos, int min_inliers,
+                     float* F, int32_t* in0, int32_t* in1)
+{
+    for (int j = 0; j < 9; ++j) F[j] = 0.0f;
+    if (n < 8) return 0;
+    if (hypotheses <= 0) hypotheses = 256;
+    float* pts = (float*)malloc((size_t)n * 4 * sizeof(float));
+    for (int m = 0; m < n; ++m) {
+        const int i = idx0[m], j = idx1[m];
+        if (i >= 0 && i < n0 && j >= 0 && j < n1) {
+            pts[4 * m + 0] = xy0[2 * i]; pts[4 * m + 1] = xy0[2 * i + 1];
+            pts[4 * m + 2] = xy1[2 * j]; pts[4 * m + 3] = xy1[2 * j + 1];
+        } else {
+            for (int d = 0; d < 4; ++d) pts[4 * m + d] = NAN;
+        }
+    }
+    const float t2 = max_sampson * max_sampson;
+    const uint64_t base = splitmix64(((uint64_t)seed << 32) ^ (uint64_t)pair_pos);
+    int* counts = (int*)malloc((size_t)hypotheses * sizeof(int));
+    float* Fs = (float*)malloc((size_t)hypotheses * 9 * sizeof(float));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int h = 0; h < hypotheses; ++h) {
+        counts[h] = -1;
+        int pick[8], got = 0;
+        for (int ctr = 0; ctr < 64 && got < 8; ++ctr) {
+            const uint64_t r = splitmix64(base + ((uint64_t)h << 8) + (uint64_t)ctr);
+            const int idx = (int)(((r >> 32) * (uint64_t)n) >> 32);
+            int dup = 0;
+            for (int k = 0; k < got; ++k) dup |= pick[k] == idx;
+            if (!dup) pick[got++] = idx;
+        }
+        if (got < 8) continue;
+        float pt[8][4];
+        for (int k = 0; k < 8; ++k) memcpy(pt[k], pts + 4 * pick[k], 4 * sizeof(float));
+        float Fh[9];
+        if (!eight_point(pt, Fh)) continue;
+        int cnt = 0;
+        for (int m = 0; m < n; ++m) cnt += inlier(Fh, pts + 4 * m, t2);
+        counts[h] = cnt;
+        memcpy(Fs + 9 * h, Fh, sizeof Fh);
+    }
+    int best = -1, bh = -1;
+    for (int h = 0; h < hypotheses; ++h)
+        if (counts[h] > best) { best = counts[h]; bh = h; }
+    int nf = 0;
+    if (bh >= 0) {
+        float Ff[9];
+        rank2(Fs + 9 * bh, Ff);
+        for (int m = 0; m < n; ++m)
+            if (inlier(Ff, pts + 4 * m, t2)) {
+                in0[nf] = idx0[m];
+                in1[nf] = idx1[m];
+                ++nf;
+            }
+        if (nf >= min_inliers && nf > 0) memcpy(F, Ff, sizeof Ff);
+        else nf = 0;
+    }
+    free(pts);
+    free(counts);
+    free(Fs);
+    return nf;
+}

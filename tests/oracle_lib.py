@@ -188,3 +188,23 @@ def mat_get_pmatch(image, other, fc_other, cap=1 << 20):
     b = np.empty(cap, np.int32)
     nm = lib().orc_mat_get_pmatch(os.fsencode(image), os.fsencode(other), fc_other, _p(a), _p(b), cap)
     return a[:nm], b[:nm]
+
+
+def geom_pair(xy0, xy1, idx0, idx1, max_sampson=2.0, hypotheses=256, seed=0, pair_pos=0, min_inliers=0):
+    """The library's stated RANSAC / eight-point / Sampson procedure for one pair, in scalar C.
+    Returns (F [3, 3] float32, inlier idx0, inlier idx1)."""
+    xy0 = np.ascontiguousarray(xy0, np.float32)
+    xy1 = np.ascontiguousarray(xy1, np.float32)
+    idx0 = np.ascontiguousarray(idx0, np.int32)
+    idx1 = np.ascontiguousarray(idx1, np.int32)
+    n = len(idx0)
+    F = np.zeros(9, np.float32)
+    in0 = np.empty(max(n, 1), np.int32)
+    in1 = np.empty(max(n, 1), np.int32)
+    fn = lib().oracle_geom_pair
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int,
+                   C.c_uint, C.c_uint, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    nf = fn(_p(xy0), len(xy0), _p(xy1), len(xy1), _p(idx0), _p(idx1), n, float(max_sampson), int(hypotheses),
+            int(seed) & 0xFFFFFFFF, int(pair_pos), int(min_inliers), _p(F), _p(in0), _p(in1))
+    return F.reshape(3, 3), in0[:nf], in1[:nf]

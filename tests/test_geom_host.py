@@ -1,0 +1,105 @@
+"""CPU checks around the geometric verification step: the oracle's RANSAC procedure recovers planted
+two-view geometry, and the inlier records of a .mat file round-trip through the writers and readers
+that stand in for MatchFile::WriteFMatch / GetIMatch / GetIMatchR.
+
+The estimate itself has no reference output to be compared with (the reference calls OpenCV, which is
+not installed): parity unpinned.  The record layout follows MatchFile.cpp:660-748 and :961-1084."""
+import os
+import struct
+
+import numpy as np
+
+import oracle_lib as orc
+import visual_slam_amd as vsm
+from visual_slam_amd import synth
+
+
+def _sampson(F, a, b):
+    x0 = np.c_[a, np.ones(len(a))]
+    x1 = np.c_[b, np.ones(len(b))]
+    Fx0 = x0 @ F.T
+    Ftx1 = x1 @ F
+    e = (x1 * Fx0).sum(1)
+    return np.abs(e) / np.sqrt(Fx0[:, 0] ** 2 + Fx0[:, 1] ** 2 + Ftx1[:, 0] ** 2 + Ftx1[:, 1] ** 2)
+
+
+def test_oracle_recovers_planted_geometry():
+    xy0, xy1, i0, i1, true, Ftrue = synth.two_view(600, seed=3, inlier_fraction=0.55, noise=0.4)
+    F, in0, in1 = orc.geom_pair(xy0, xy1, i0, i1, max_sampson=2.0, hypotheses=512, seed=9)
+    got = set(zip(in0.tolist(), in1.tolist()))
+    want = set(zip(i0[true].tolist(), i1[true].tolist()))
+    assert len(got & want) >= 0.9 * len(want)          # nearly all true correspondences are inliers
+    assert len(got - want) <= 0.1 * len(want)          # few wrong pairings lie on an epipolar line by chance
+    F = F.astype(np.float64)
+    assert abs(np.linalg.norm(F) - 1.0) < 1e-5
+    assert np.linalg.svd(F, compute_uv=False)[2] < 1e-6  # rank 2
+    # the true correspondences satisfy the estimated geometry to about the noise level
+    d = _sampson(F, xy0[i0[true]].astype(np.float64), xy1[i1[true]].astype(np.float64))
+    assert np.median(d) < 1.0
+    # lists come in match order
+    pos = {(a, b): k for k, (a, b) in enumerate(zip(i0.tolist(), i1.tolist()))}
+    ks = [pos[p] for p in zip(in0.tolist(), in1.tolist())]
+    assert ks == sorted(ks)
+
+
+def test_oracle_degenerate_inputs():
+    xy0, xy1, i0, i1, _, _ = synth.two_view(40, seed=4)
+    F, in0, in1 = orc.geom_pair(xy0, xy1, i0[:7], i1[:7])          # fewer than eight matches
+    assert len(in0) == 0 and not F.any()
+    same = np.zeros((40, 2), np.float32)                            # all keypoints coincide
+    F, in0, in1 = orc.geom_pair(same, same, i0, i1)
+    assert len(in0) == 0 and not F.any()
+    bad = i0.copy()
+    bad[::2] = 10**6                                                # out-of-range feature indices never count
+    F, in0, in1 = orc.geom_pair(xy0, xy1, bad, i1, hypotheses=64)
+    assert (in0 < 40).all()
+    F, in0, in1 = orc.geom_pair(xy0, xy1, i0, i1, min_inliers=41)   # cannot be reached
+    assert len(in0) == 0 and not F.any()
+
+
+def test_inlier_records_round_trip(tmp_path):
+    a, b = str(tmp_path / "imgA"), str(tmp_path / "sub" / "imgB")
+    os.makedirs(os.path.dirname(b))
+    rng = np.random.default_rng(5)
+    nm = 37
+    p0 = rng.permutation(500)[:nm].astype(np.int32)
+    p1 = rng.permutation(400)[:nm].astype(np.int32)
+    vsm.write_pmatch(a, b, 500, 400, p0, p1)
+    sel = np.sort(rng.permutation(nm)[:21])
+    F = rng.standard_normal((3, 3)).astype(np.float32)
+    assert vsm.write_fmatch(a, b, p0[sel], p1[sel], F) == 1
+    # putative lists are untouched
+    g0, g1 = vsm.get_pmatch(a, b, 400)
+    np.testing.assert_array_equal(g0, p0)
+    np.testing.assert_array_equal(g1, p1)
+    nm_a, Fa, r0, r1 = vsm.get_imatch(a, b, 400)
+    assert nm_a == nm
+    np.testing.assert_array_equal(Fa, F)
+    np.testing.assert_array_equal(r0, p0[sel])
+    np.testing.assert_array_equal(r1, p1[sel])
+    # the other image's file holds the transposed matrix and the swapped rows ...
+    nm_b, Fb, s0, s1 = vsm.get_imatch(b, a, 500)
+    assert nm_b == nm
+    np.testing.assert_array_equal(Fb, F.T)
+    np.testing.assert_array_equal(s0, p1[sel])
+    np.testing.assert_array_equal(s1, p0[sel])
+    # ... which the reversed reader turns back
+    nm_r, Fr, t0, t1 = vsm.get_imatch_r(b, a, 500)
+    np.testing.assert_array_equal(Fr, F)
+    np.testing.assert_array_equal(t0, p0[sel])
+    np.testing.assert_array_equal(t1, p1[sel])
+    assert vsm.get_match_count(a, b) == (nm, 21)
+    # bytes: NM, record version 'MRV3', NF, then F row-major at offset 4 + 4 + 16 of the block
+    raw = open(a + ".mat", "rb").read()
+    loc = struct.unpack_from("<5i", raw, 20)
+    blk = loc[1]
+    assert struct.unpack_from("<i", raw, blk)[0] == nm
+    assert raw[blk + 4:blk + 8] == b"MRV3"
+    assert struct.unpack_from("<i", raw, blk + 8)[0] == 21
+    np.testing.assert_array_equal(np.frombuffer(raw, np.float32, 9, blk + 4 + 4 + 16).reshape(3, 3), F)
+    inl = np.frombuffer(raw, np.int32, 42, blk + 4 + 184 + nm * 8)
+    np.testing.assert_array_equal(inl[:21], p0[sel])
+    np.testing.assert_array_equal(inl[21:], p1[sel])
+    # a wrong feature count is rejected as the reference does, and an unknown partner reports nothing
+    assert vsm.get_imatch(a, b, 399)[0] == 0
+    assert vsm.write_fmatch(a, str(tmp_path / "other"), p0[:1], p1[:1], F) == 0

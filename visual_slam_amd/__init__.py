@@ -32,6 +32,9 @@ from .host import (  # noqa: F401
     get_pmatch,
     get_pmatch_r,
     get_match_count,
+    write_fmatch,
+    get_imatch,
+    get_imatch_r,
     nearest_embed,
     mutual_nn_match,
 )
@@ -43,5 +46,6 @@ __all__ = [
     "generate_imagePairs", "generate_exhaustive_pairs", "get_list_matching_pairs",
     "save_matching_sfm", "save_feature_locations", "read_feature_locations",
     "read_sift", "write_sift", "write_pmatch", "get_pmatch", "get_pmatch_r", "get_match_count",
+    "write_fmatch", "get_imatch", "get_imatch_r",
     "nearest_embed", "mutual_nn_match",
 ]

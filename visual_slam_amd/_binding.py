@@ -97,7 +97,21 @@ SIGNATURES = {
     "vsm_mat_get_pmatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "vsm_mat_get_pmatch_r": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "vsm_mat_get_match_count": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vsm_upload_xy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "vsm_verify_matches": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_longlong]),
+    "vsm_mat_write_fmatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsm_mat_get_imatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.POINTER(C.c_int),
+                                     C.c_void_p, C.c_void_p, C.c_int]),
+    "vsm_mat_get_imatch_r": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.POINTER(C.c_int),
+                                       C.c_void_p, C.c_void_p, C.c_int]),
 }
+
+
+class GeomParams(C.Structure):
+    """vsm_geom_params"""
+    _fields_ = [("max_sampson", C.c_float), ("hypotheses", C.c_int), ("seed", C.c_uint), ("min_inliers", C.c_int)]
 
 _lib = None
 
@@ -306,6 +320,48 @@ class Matcher:
         self._check(self._l.vsm_nearest_embed(self._h, _ptr(x), b, d, npts, _ptr(emb), emb.shape[1],
                                               _ptr(argmin), _ptr(res)))
         return (res.reshape(x.shape) if want_result else None), argmin.reshape((b,) + tuple(x.shape[2:]))
+
+    # ---- geometric verification ---------------------------------------------------------
+    def upload_xy(self, xy):
+        """Keypoint locations of one image, n x (x, y)."""
+        xy = np.ascontiguousarray(xy, dtype=np.float32)
+        if xy.ndim != 2 or xy.shape[1] != 2:
+            raise ValueError("expected an n x 2 float32 array")
+        sid = self._check(self._l.vsm_upload_xy(self._h, _ptr(xy), xy.shape[0]))
+        self._kinds[sid] = ("xy", xy.shape[0])
+        return sid
+
+    def verify_matches(self, xy_pairs, offsets=None, idx0=None, idx1=None, max_sampson=2.0, hypotheses=256, seed=0,
+                       min_inliers=0, cap=None):
+        """Fundamental matrix and inlier matches per pair.  With offsets/idx0/idx1 None the putative
+        matches are the lists of the last collected submission, read on the device (cap: their total,
+        as match_pairs_device returned it; without it the call may run twice to size the buffers).
+        Returns (F [npairs, 3, 3], nf [npairs], in_offsets, in_idx0, in_idx1)."""
+        xy_pairs = np.ascontiguousarray(xy_pairs, dtype=np.int32).reshape(-1, 2)
+        npairs = xy_pairs.shape[0]
+        g = GeomParams(float(max_sampson), int(hypotheses), int(seed) & 0xFFFFFFFF, int(min_inliers))
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, np.int64)
+            idx0 = np.ascontiguousarray(idx0, np.int32)
+            idx1 = np.ascontiguousarray(idx1, np.int32)
+            cap = int(offsets[-1]) if npairs else 0
+        else:
+            cap = int(cap) if cap is not None else 0
+        F = np.zeros((npairs, 3, 3), np.float32)
+        nf = np.zeros(npairs, np.int32)
+        in_off = np.zeros(npairs + 1, np.int64)
+        in0 = np.empty(max(cap, 1), np.int32)
+        in1 = np.empty(max(cap, 1), np.int32)
+        got = self._l.vsm_verify_matches(self._h, _ptr(xy_pairs), npairs, _ptr(offsets), _ptr(idx0), _ptr(idx1),
+                                         C.byref(g), _ptr(F), _ptr(nf), _ptr(in_off), _ptr(in0), _ptr(in1), cap)
+        if got == -4:   # VSM_ECAP: size the buffers from the offsets and run again
+            cap = int(in_off[-1])
+            in0 = np.empty(max(cap, 1), np.int32)
+            in1 = np.empty(max(cap, 1), np.int32)
+            got = self._l.vsm_verify_matches(self._h, _ptr(xy_pairs), npairs, _ptr(offsets), _ptr(idx0), _ptr(idx1),
+                                             C.byref(g), _ptr(F), _ptr(nf), _ptr(in_off), _ptr(in0), _ptr(in1), cap)
+        got = self._check(got)
+        return F, nf, in_off, in0[:got], in1[:got]
 
     # ---- measurement --------------------------------------------------------------------
     def set_scratch_budget(self, nbytes):

@@ -831,3 +831,102 @@ extern "C" int vsm_mat_get_match_count(const char* image, const char* other, int
     if (nf) *nf = counts[2];
     return 1;
 }
+
+// ---- inlier records ---------------------------------------------------------------------
+namespace {
+
+// MatchFile::WriteIMatch(image_match, reverse, NM = 0, tvg, inliers), MatchFile.cpp:660-748, for the
+// geometry WriteFMatch builds (TwoViewGeometry(NF, F), MatchFile.h:85-92).  The record must exist and
+// have room, which every record written by WritePMatch has (block = 184 + max(NM, 8) * 24 bytes against
+// 188 + (NM + NF) * 8 needed, NF <= NM); the reference's re-allocation branch (:690-719) moves the
+// directory entry without the putative lists and is not reproduced.
+int mat_put_inliers(const std::string& image, const std::string& other, bool reverse, int nf,
+                    const int32_t* row_a, const int32_t* row_b, const float* F)
+{
+    MatFile mf;
+    if (!mf.open(image, true)) return VSM_EIO;
+    const int idx = mf.find(relative_name(image, other));
+    if (idx < 0) return 0;
+    const MatRecLoc* loc = mf.rec(idx);
+    int32_t nm = 0;
+    if (mf.read_at(loc->read_loc, &nm, 4) != 4 || nm < 0) return 0;
+    const long long need = (1 + ((long long)nm + nf) * 2) * 4 + (long long)sizeof(MatRecord);
+    if (need > loc->block_size) return VSM_EUNSUPPORTED;
+    MatRecord rec;
+    memset(&rec, 0, sizeof rec);
+    rec.version = kRecVersion;
+    rec.tvg.GE = 100.0f;
+    rec.tvg.NF = nf;
+    if (nf > 0)
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) rec.tvg.F[i][j] = reverse ? F[3 * j + i] : F[3 * i + j];   // SetGeometryR transposes
+    if (!mf.write_at((off_t)loc->read_loc + 4, &rec, sizeof rec)) return VSM_EIO;
+    if (nf > 0) {
+        const off_t at = (off_t)loc->read_loc + 4 + (off_t)sizeof rec + (off_t)nm * 8;
+        const int32_t* first = reverse ? row_b : row_a;
+        const int32_t* second = reverse ? row_a : row_b;
+        if (!mf.write_at(at, first, (size_t)nf * 4) || !mf.write_at(at + (off_t)nf * 4, second, (size_t)nf * 4)) return VSM_EIO;
+    }
+    return 1;
+}
+
+}  // namespace
+
+extern "C" int vsm_mat_write_fmatch(const char* image1, const char* image2, int nf, const int32_t* idx1,
+                                    const int32_t* idx2, const float* F)
+{
+    if (!image1 || !image2 || !image1[0] || !image2[0] || nf < 0 || (nf > 0 && (!idx1 || !idx2 || !F))) return VSM_EINVAL;
+    if (strlen(image1) + 5 > (size_t)kMaxPath || strlen(image2) + 5 > (size_t)kMaxPath) return VSM_EINVAL;
+    const int a = mat_put_inliers(image1, image2, false, nf, idx1, idx2, F);
+    if (a < 0) return a;
+    const int b = mat_put_inliers(image2, image1, true, nf, idx1, idx2, F);
+    if (b < 0) return b;
+    return a == 1 && b == 1 ? 1 : 0;
+}
+
+static int mat_get_inliers(const char* image, const char* other, int fc_other, bool reverse, float* F, int* nf,
+                           int32_t* row0, int32_t* row1, int cap)
+{
+    if (nf) *nf = 0;
+    if (F) memset(F, 0, 9 * sizeof(float));
+    if (!image || !other) return 0;
+    MatFile mf;
+    if (!mf.open(image, false)) return 0;
+    const int idx = mf.find(relative_name(image, other));
+    if (idx < 0) return 0;
+    const MatRecLoc* loc = mf.rec(idx);
+    if (loc->fcount != fc_other) return 0;   // MatchFile.cpp:975
+    int32_t nm = 0;
+    MatRecord rec;
+    if (mf.read_at(loc->read_loc, &nm, 4) != 4) return 0;
+    if (mf.read_at((off_t)loc->read_loc + 4, &rec, sizeof rec) != (ssize_t)sizeof rec) return 0;
+    if (nm > loc->fcount || nm < 0) return 0;                                          // :988
+    if (nm == 0 || rec.version != kRecVersion || rec.tvg.NF > loc->fcount) return 0;   // :995
+    const int n = rec.tvg.NF;
+    if (n > 0) {
+        if (F)
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) F[3 * i + j] = reverse ? rec.tvg.F[j][i] : rec.tvg.F[i][j];
+        const int take = std::min(n, std::max(cap, 0));
+        const off_t at = (off_t)loc->read_loc + 4 + (off_t)sizeof rec + (off_t)nm * 8;
+        // :1011 reads both rows in stored order; :1074-1075 reads the first stored row into inliers[1]
+        int32_t* first = reverse ? row1 : row0;
+        int32_t* second = reverse ? row0 : row1;
+        if (first && mf.read_at(at, first, (size_t)take * 4) != (ssize_t)take * 4) return 0;
+        if (second && mf.read_at(at + (off_t)n * 4, second, (size_t)take * 4) != (ssize_t)take * 4) return 0;
+    }
+    if (nf) *nf = n > 0 ? n : 0;
+    return nm;
+}
+
+extern "C" int vsm_mat_get_imatch(const char* image, const char* other, int fc_other, float* F, int* nf,
+                                  int32_t* row0, int32_t* row1, int cap)
+{
+    return mat_get_inliers(image, other, fc_other, false, F, nf, row0, row1, cap);
+}
+
+extern "C" int vsm_mat_get_imatch_r(const char* image, const char* other, int fc_other, float* F, int* nf,
+                                    int32_t* row0, int32_t* row1, int cap)
+{
+    return mat_get_inliers(image, other, fc_other, true, F, nf, row0, row1, cap);
+}

@@ -1,0 +1,391 @@
+// Two-view geometric verification of putative matches: a fundamental matrix per image pair by
+// RANSAC over the normalised eight-point solve, Sampson-distance inliers.  This is the step that
+// follows matching in the workflow the reference feeds (TwoViewGeometry + inlier lists of a match
+// record, MatchFile.h:68-161 and MatchFile.cpp:596-748; cv2.findEssentialMat + RANSAC in
+// models/utils.py:288-312).  The reference holds no estimator of its own (it calls OpenCV), so the
+// algorithm below is this library's, stated operation by operation so that the CPU checker can follow
+// it bit for bit:
+//
+//   sample h of pair p : eight distinct matches drawn from a counter-based generator (splitmix64)
+//   solve              : Hartley normalisation of the eight points (per image), the 8 x 9 system of
+//                        x1^T F x0 = 0, Gaussian elimination with complete pivoting, free variable 1,
+//                        back substitution, unit norm, de-normalisation, unit Frobenius norm (f64)
+//   score              : F rounded to f32; a match is an inlier when e^2 < t^2 * (a0^2 + a1^2 + b0^2 + b1^2)
+//                        with a = F x0, b = F^T x1, e = x1 . a (f32, no contraction)
+//   winner             : most inliers, lowest sample index among equals
+//   finish             : rank 2 enforced on the winner (f64 Jacobi eigenvectors of F^T F, the direction
+//                        of the smallest eigenvalue projected out), unit Frobenius norm, rounded to
+//                        f32, inliers re-scored with that matrix and listed in match order
+//
+// Every operation is an IEEE add, multiply, divide, square root or compare in a fixed order: results
+// do not depend on the grid, and the file is compiled without floating-point contraction.
+#include <hip/hip_runtime.h>
+
+#include "vsm_internal.h"
+
+namespace vsm {
+
+namespace {
+
+constexpr int kGeomThreads = 128;     // hypothesis kernel: threads (samples in flight) per image pair
+constexpr int kGeomEmitThreads = 256;
+
+__host__ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// coordinates of the putative matches of all pairs, gathered once: (x0, y0, x1, y1) per match
+__global__ void geom_gather_kernel(const GeomPair* __restrict__ pairs, int npairs,
+                                   const int32_t* __restrict__ idx0, const int32_t* __restrict__ idx1,
+                                   float4* __restrict__ coords)
+{
+    const GeomPair gp = pairs[blockIdx.y];
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < gp.n; m += gridDim.x * blockDim.x) {
+        const int i = idx0[gp.off + m], j = idx1[gp.off + m];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i >= 0 && i < gp.n0 && j >= 0 && j < gp.n1) {
+            const float2 a = reinterpret_cast<const float2*>(gp.xy0)[i];
+            const float2 b = reinterpret_cast<const float2*>(gp.xy1)[j];
+            v = make_float4(a.x, a.y, b.x, b.y);
+        } else {
+            v.x = v.y = v.z = v.w = __builtin_nanf("");   // never an inlier, never a usable sample
+        }
+        coords[gp.off + m] = v;
+    }
+}
+
+__device__ __forceinline__ bool sampson_inlier(const float (&F)[9], const float4 p, float t2)
+{
+    const float a0 = (F[0] * p.x + F[1] * p.y) + F[2];
+    const float a1 = (F[3] * p.x + F[4] * p.y) + F[5];
+    const float a2 = (F[6] * p.x + F[7] * p.y) + F[8];
+    const float b0 = (F[0] * p.z + F[3] * p.w) + F[6];
+    const float b1 = (F[1] * p.z + F[4] * p.w) + F[7];
+    const float e = (p.z * a0 + p.w * a1) + a2;
+    const float den = ((a0 * a0 + a1 * a1) + b0 * b0) + b1 * b1;
+    return e * e < t2 * den;
+}
+
+// The eight-point solve of one sample.  A lives in LDS, element (r, c) of thread t at
+// A[(r * 9 + c) * kGeomThreads + t] (rows and columns are swapped by run-time indices).
+__device__ bool solve_sample(double* __restrict__ A, const float4 (&pt)[8], float (&Fout)[9])
+{
+    const int t = threadIdx.x;
+    auto at = [&](int r, int c) -> double& { return A[(r * 9 + c) * kGeomThreads + t]; };
+    // Hartley normalisation per image
+    double cx0 = 0, cy0 = 0, cx1 = 0, cy1 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        cx0 += (double)pt[k].x; cy0 += (double)pt[k].y;
+        cx1 += (double)pt[k].z; cy1 += (double)pt[k].w;
+    }
+    cx0 /= 8.0; cy0 /= 8.0; cx1 /= 8.0; cy1 /= 8.0;
+    double md0 = 0, md1 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double dx0 = (double)pt[k].x - cx0, dy0 = (double)pt[k].y - cy0;
+        const double dx1 = (double)pt[k].z - cx1, dy1 = (double)pt[k].w - cy1;
+        md0 += sqrt(dx0 * dx0 + dy0 * dy0);
+        md1 += sqrt(dx1 * dx1 + dy1 * dy1);
+    }
+    md0 /= 8.0; md1 /= 8.0;
+    if (!(md0 > 0.0) || !(md1 > 0.0)) return false;   // also false for NaN coordinates
+    const double s0 = 1.4142135623730951 / md0, s1 = 1.4142135623730951 / md1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double x0 = ((double)pt[k].x - cx0) * s0, y0 = ((double)pt[k].y - cy0) * s0;
+        const double x1 = ((double)pt[k].z - cx1) * s1, y1 = ((double)pt[k].w - cy1) * s1;
+        at(k, 0) = x1 * x0; at(k, 1) = x1 * y0; at(k, 2) = x1;
+        at(k, 3) = y1 * x0; at(k, 4) = y1 * y0; at(k, 5) = y1;
+        at(k, 6) = x0;      at(k, 7) = y0;      at(k, 8) = 1.0;
+    }
+    // elimination with complete pivoting; perm: column j of the working matrix is unknown perm[j]
+    unsigned long long perm = 0x876543210ull;
+    for (int k = 0; k < 8; ++k) {
+        double best = 0.0;
+        int pr = k, pc = k;
+        for (int r = k; r < 8; ++r)
+            for (int c = k; c < 9; ++c) {
+                const double v = fabs(at(r, c));
+                if (v > best) { best = v; pr = r; pc = c; }
+            }
+        if (!(best > 0.0)) return false;
+        if (pr != k)
+            for (int c = 0; c < 9; ++c) { const double tmp = at(k, c); at(k, c) = at(pr, c); at(pr, c) = tmp; }
+        if (pc != k) {
+            for (int r = 0; r < 8; ++r) { const double tmp = at(r, k); at(r, k) = at(r, pc); at(r, pc) = tmp; }
+            const unsigned long long a = (perm >> (4 * k)) & 15ull, b = (perm >> (4 * pc)) & 15ull;
+            perm &= ~((15ull << (4 * k)) | (15ull << (4 * pc)));
+            perm |= (b << (4 * k)) | (a << (4 * pc));
+        }
+        const double piv = at(k, k);
+        for (int r = k + 1; r < 8; ++r) {
+            const double f = at(r, k) / piv;
+            for (int c = k + 1; c < 9; ++c) at(r, c) -= f * at(k, c);
+        }
+    }
+    // back substitution with the free unknown (working column 8) set to 1
+    double x[9];
+    x[8] = 1.0;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = k + 1; c < 9; ++c) s += at(k, c) * x[c];
+        x[k] = -s / at(k, k);
+    }
+    // unknowns back in their places (row 0 of A is free now), unit norm
+#pragma unroll
+    for (int j = 0; j < 9; ++j) at(0, (int)((perm >> (4 * j)) & 15ull)) = x[j];
+    double f[9], nn = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { f[j] = at(0, j); nn += f[j] * f[j]; }
+    nn = sqrt(nn);
+    if (!(nn > 0.0)) return false;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) f[j] /= nn;
+    // F = T1^T Fn T0 with T = [s 0 -s cx; 0 s -s cy; 0 0 1]
+    double M[9], G[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        M[3 * i + 0] = f[3 * i + 0] * s0;
+        M[3 * i + 1] = f[3 * i + 1] * s0;
+        M[3 * i + 2] = f[3 * i + 2] - (M[3 * i + 0] * cx0 + M[3 * i + 1] * cy0);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        G[j] = s1 * M[j];
+        G[3 + j] = s1 * M[3 + j];
+        G[6 + j] = M[6 + j] - (G[j] * cx1 + G[3 + j] * cy1);
+    }
+    double fn = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) fn += G[j] * G[j];
+    fn = sqrt(fn);
+    if (!(fn > 0.0) || !(fn < 1e300)) return false;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) Fout[j] = (float)(G[j] / fn);
+    return true;
+}
+
+// one workgroup per image pair; thread t runs samples t, t + 128, ...
+__global__ __launch_bounds__(kGeomThreads)
+void geom_ransac_kernel(const GeomPair* __restrict__ pairs, const float4* __restrict__ coords,
+                        GeomRule rule, float* __restrict__ Fbest, int32_t* __restrict__ best_count)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* A = reinterpret_cast<double*>(smem);
+    __shared__ unsigned long long s_key[kGeomThreads];
+    const GeomPair gp = pairs[blockIdx.x];
+    const int t = threadIdx.x;
+    const float4* __restrict__ pts = coords + gp.off;
+    const int n = gp.n;
+    const float t2 = rule.max_sampson * rule.max_sampson;
+    const unsigned long long base = splitmix64(((unsigned long long)rule.seed << 32) ^ (unsigned long long)(unsigned)blockIdx.x);
+
+    int mycount = -1, myh = 0;
+    float myF[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) myF[j] = 0.0f;
+    if (n >= 8) {
+        for (int h = t; h < rule.hypotheses; h += kGeomThreads) {
+            // eight distinct matches
+            int pick[8];
+            int got = 0;
+            for (int ctr = 0; ctr < 64 && got < 8; ++ctr) {
+                const unsigned long long r = splitmix64(base + ((unsigned long long)h << 8) + (unsigned long long)ctr);
+                const int idx = (int)(((r >> 32) * (unsigned long long)n) >> 32);
+                bool dup = false;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dup = dup || (k < got && pick[k] == idx);
+                if (!dup) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k == got) pick[k] = idx;
+                    ++got;
+                }
+            }
+            if (got < 8) continue;
+            float4 pt[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pt[k] = pts[pick[k]];
+            float F[9];
+            if (!solve_sample(A, pt, F)) continue;
+            int cnt = 0;
+            for (int m = 0; m < n; ++m) cnt += sampson_inlier(F, pts[m], t2) ? 1 : 0;
+            if (cnt > mycount) {   // samples come in ascending order: the first of equals stays
+                mycount = cnt;
+                myh = h;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) myF[j] = F[j];
+            }
+        }
+    }
+    // most inliers, then lowest sample index
+    s_key[t] = mycount < 0 ? 0ull : (((unsigned long long)(unsigned)(mycount + 1)) << 32) | (unsigned)(0x7fffffff - myh);
+    __syncthreads();
+    for (int d = kGeomThreads / 2; d > 0; d >>= 1) {
+        if (t < d && s_key[t + d] > s_key[t]) s_key[t] = s_key[t + d];
+        __syncthreads();
+    }
+    const unsigned long long win = s_key[0];
+    if (win == 0ull) {
+        if (t == 0) {
+            best_count[blockIdx.x] = -1;
+            for (int j = 0; j < 9; ++j) Fbest[(size_t)blockIdx.x * 9 + j] = 0.0f;
+        }
+        return;
+    }
+    const unsigned long long mine = mycount < 0 ? 0ull : (((unsigned long long)(unsigned)(mycount + 1)) << 32) | (unsigned)(0x7fffffff - myh);
+    if (mine == win) {   // exactly one thread: sample indices are distinct
+        best_count[blockIdx.x] = mycount;
+        for (int j = 0; j < 9; ++j) Fbest[(size_t)blockIdx.x * 9 + j] = myF[j];
+    }
+}
+
+// rank 2: remove the right singular direction of the smallest singular value (f64 cyclic Jacobi on F^T F)
+__device__ void enforce_rank2(const float* __restrict__ Fin, float (&Fout)[9])
+{
+    double F[9], S[9], V[9];
+    for (int j = 0; j < 9; ++j) F[j] = (double)Fin[j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            S[3 * i + j] = (F[i] * F[j] + F[3 + i] * F[3 + j]) + F[6 + i] * F[6 + j];   // (F^T F)[i][j]
+            V[3 * i + j] = i == j ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+            const double apq = S[3 * p + q];
+            if (apq == 0.0) continue;
+            const double theta = (S[3 * q + q] - S[3 * p + p]) / (2.0 * apq);
+            const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+            // S <- J^T S J, V <- V J with J the rotation in the (p, q) plane
+            for (int k = 0; k < 3; ++k) {
+                const double skp = S[3 * k + p], skq = S[3 * k + q];
+                S[3 * k + p] = c * skp - s * skq;
+                S[3 * k + q] = s * skp + c * skq;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double spk = S[3 * p + k], sqk = S[3 * q + k];
+                S[3 * p + k] = c * spk - s * sqk;
+                S[3 * q + k] = s * spk + c * sqk;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double vkp = V[3 * k + p], vkq = V[3 * k + q];
+                V[3 * k + p] = c * vkp - s * vkq;
+                V[3 * k + q] = s * vkp + c * vkq;
+            }
+        }
+    }
+    int im = 0;
+    if (S[4] < S[0]) im = 1;
+    if (S[8] < S[3 * im + im]) im = 2;
+    const double v0 = V[im], v1 = V[3 + im], v2 = V[6 + im];
+    double G[9], fn = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        const double fv = (F[3 * i] * v0 + F[3 * i + 1] * v1) + F[3 * i + 2] * v2;
+        G[3 * i + 0] = F[3 * i + 0] - fv * v0;
+        G[3 * i + 1] = F[3 * i + 1] - fv * v1;
+        G[3 * i + 2] = F[3 * i + 2] - fv * v2;
+    }
+    for (int j = 0; j < 9; ++j) fn += G[j] * G[j];
+    fn = sqrt(fn);
+    for (int j = 0; j < 9; ++j) Fout[j] = fn > 0.0 ? (float)(G[j] / fn) : 0.0f;
+}
+
+// one workgroup per pair: final matrix, inliers in match order
+__global__ __launch_bounds__(kGeomEmitThreads)
+void geom_emit_kernel(const GeomPair* __restrict__ pairs, const float4* __restrict__ coords,
+                      const int32_t* __restrict__ idx0, const int32_t* __restrict__ idx1, GeomRule rule,
+                      const float* __restrict__ Fbest, const int32_t* __restrict__ best_count,
+                      float* __restrict__ Fout, int32_t* __restrict__ counts,
+                      int32_t* __restrict__ slot_i0, int32_t* __restrict__ slot_i1)
+{
+    __shared__ float s_F[9];
+    __shared__ int wsum[kGeomEmitThreads / 64];
+    __shared__ int base_s;
+    const GeomPair gp = pairs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool have = best_count[blockIdx.x] >= 0;
+    if (tid == 0) {
+        base_s = 0;
+        float F[9];
+        if (have) enforce_rank2(Fbest + (size_t)blockIdx.x * 9, F);
+        for (int j = 0; j < 9; ++j) s_F[j] = have ? F[j] : 0.0f;
+    }
+    __syncthreads();
+    float F[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) F[j] = s_F[j];
+    const float t2 = rule.max_sampson * rule.max_sampson;
+    const float4* __restrict__ pts = coords + gp.off;
+    for (int m0 = 0; have && m0 < gp.n; m0 += kGeomEmitThreads) {
+        const int m = m0 + tid;
+        const bool ok = m < gp.n && sampson_inlier(F, pts[m], t2);
+        const unsigned long long bal = __ballot(ok);
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < kGeomEmitThreads / 64; ++w) {
+            if (w < wave) woff += wsum[w];
+            tot += wsum[w];
+        }
+        const int base = base_s;
+        __syncthreads();
+        if (tid == 0) base_s = base + tot;
+        if (ok) {
+            const size_t o = gp.off + base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+            slot_i0[o] = idx0[gp.off + m];
+            slot_i1[o] = idx1[gp.off + m];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const bool keep = have && base_s >= rule.min_inliers && base_s > 0;
+        counts[blockIdx.x] = keep ? base_s : 0;
+        for (int j = 0; j < 9; ++j) Fout[(size_t)blockIdx.x * 9 + j] = keep ? F[j] : 0.0f;
+    }
+}
+
+__global__ void geom_pack_pairs_kernel(const GeomPair* __restrict__ gp, int npairs, SiftPair* __restrict__ sp)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    SiftPair s{};
+    s.nA = gp[p].n;
+    s.out0_off = gp[p].off;
+    sp[p] = s;
+}
+
+}  // namespace
+
+size_t geom_lds_bytes() { return (size_t)72 * kGeomThreads * sizeof(double); }
+
+void launch_geom_verify(const GeomPair* pairs, int npairs, int max_matches, const int32_t* idx0, const int32_t* idx1,
+                        const GeomRule& rule, float4* coords, float* Fbest, int32_t* best_count,
+                        float* Fout, int32_t* counts, int32_t* slot_i0, int32_t* slot_i1, SiftPair* pack_pairs,
+                        hipStream_t s)
+{
+    if (npairs <= 0) return;
+    const int gx = std::max(1, std::min(64, (max_matches + 255) / 256));
+    hipLaunchKernelGGL(geom_gather_kernel, dim3(gx, npairs), dim3(256), 0, s, pairs, npairs, idx0, idx1, coords);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(geom_ransac_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom_lds_bytes());
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(geom_ransac_kernel, dim3(npairs), dim3(kGeomThreads), geom_lds_bytes(), s,
+                       pairs, coords, rule, Fbest, best_count);
+    hipLaunchKernelGGL(geom_emit_kernel, dim3(npairs), dim3(kGeomEmitThreads), 0, s,
+                       pairs, coords, idx0, idx1, rule, Fbest, best_count, Fout, counts, slot_i0, slot_i1);
+    hipLaunchKernelGGL(geom_pack_pairs_kernel, dim3((npairs + 255) / 256), dim3(256), 0, s, pairs, npairs, pack_pairs);
+}
+
+}  // namespace vsm

@@ -68,12 +68,12 @@ struct HostBuf {  // pinned
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-enum SetKind { SET_FREE = 0, SET_U8 = 1, SET_F32 = 2 };
+enum SetKind { SET_FREE = 0, SET_U8 = 1, SET_F32 = 2, SET_XY = 3 };
 
 struct DescSet {
     SetKind kind = SET_FREE;
     int n = 0, n_pad = 0, dim = 0;
-    void* frag = nullptr;  // u8: fragment-major int8; f32: fragment-major float
+    void* frag = nullptr;  // u8: fragment-major int8; f32: fragment-major float; xy: n x (x, y) floats
     void* nrm = nullptr;   // u8: int32 nrm8; f32: float squared norms
     void* shadow = nullptr;  // f32 only: bf16 operand-order copy + constants of the coarse pass
     Bf16Shadow shadow_view() const { return bf16_shadow_view(shadow, n_pad, dim); }
@@ -89,7 +89,7 @@ struct vsm_ctx {
     // workspace (grow-only)
     DevBuf d_pairs, d_items, d_rr1, d_rrj, d_rr2, d_colpart, d_cand;
     DevBuf d_slot0, d_slot1, d_slotd, d_counts;
-    DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_flag, d_probs, d_refs;
+    DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_flag, d_probs, d_refs, d_geom;
     // float sets: 0 = bf16 coarse pass + exact re-rank (exact kernel when a survivor list overflows), 1 = exact kernel only
     int f32_mode = 0, last_f32_path = -1;
     HostBuf h_small, h_probs, h_refs;
@@ -331,6 +331,7 @@ int set_kind_of_pair(vsm_ctx* c, int set0, int set1, SetKind* kind)
     const DescSet* B = get_set(c, set1);
     if (!A || !B) return fail(c, VSM_EINVAL, "unknown set id (%d, %d)", set0, set1);
     if (A->kind != B->kind) return fail(c, VSM_EINVAL, "sets %d and %d hold different descriptor kinds", set0, set1);
+    if (A->kind != SET_U8 && A->kind != SET_F32) return fail(c, VSM_EINVAL, "sets %d and %d hold no descriptors", set0, set1);
     if (A->kind == SET_F32 && A->dim != B->dim) return fail(c, VSM_EINVAL, "sets %d and %d differ in dimension", set0, set1);
     *kind = A->kind;
     return VSM_OK;
@@ -397,7 +398,7 @@ extern "C" void vsm_destroy(vsm_ctx* c)
     DevBuf* bufs[] = {&c->d_pairs, &c->d_items, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart, &c->d_cand,
                       &c->d_slot0, &c->d_slot1, &c->d_slotd, &c->d_counts, &c->d_dense0, &c->d_dense1,
                       &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage, &c->d_coarse, &c->d_flag,
-                      &c->d_probs, &c->d_refs};
+                      &c->d_probs, &c->d_refs, &c->d_geom};
     for (DevBuf* b : bufs) b->release();
     for (auto& r : c->slots) {
         r.d_offsets.release();
@@ -1312,6 +1313,133 @@ extern "C" int vsm_knn2(vsm_ctx* c, int set_q, int set_db, int metric,
     if (d2) HIPCHK(c, hipMemcpyAsync(d2, c->d_knn2.p, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return A->n;
+}
+
+// ---------------------------------------------------------------------------------
+// geometric verification
+// ---------------------------------------------------------------------------------
+extern "C" int vsm_upload_xy(vsm_ctx* c, const float* xy, int n)
+{
+    if (!c) return VSM_EINVAL;
+    if (n < 0 || (n > 0 && !xy)) return fail(c, VSM_EINVAL, "bad keypoint buffer (n=%d)", n);
+    HIPCHK(c, hipSetDevice(c->device));
+    DescSet s;
+    s.kind = SET_XY;
+    s.n = n;
+    s.n_pad = n;
+    s.dim = 2;
+    if (n > 0) {
+        HIPCHK(c, hipMalloc(&s.frag, (size_t)n * 2 * sizeof(float)));
+        hipError_t e = hipMemcpy(s.frag, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(s.frag);
+            return fail(c, VSM_ENODEV, "keypoint copy: %s", hipGetErrorString(e));
+        }
+    }
+    const int id = new_set_slot(c);
+    c->sets[id] = s;
+    return id;
+}
+
+extern "C" long long vsm_verify_matches(vsm_ctx* c, const int32_t* xy_pairs, int npairs, const int64_t* offsets,
+                                        const int32_t* idx0, const int32_t* idx1, const vsm_geom_params* g,
+                                        float* F, int32_t* nf, int64_t* in_offsets, int32_t* in_idx0,
+                                        int32_t* in_idx1, long long cap)
+{
+    if (!c) return VSM_EINVAL;
+    if (npairs < 0 || (npairs > 0 && !xy_pairs) || !g || !in_offsets) return fail(c, VSM_EINVAL, "bad argument");
+    if (npairs > 65535) return fail(c, VSM_EINVAL, "%d pairs in one call (limit 65535)", npairs);
+    if (!(g->max_sampson > 0.0f) || g->hypotheses < 0 || g->hypotheses > (1 << 20))
+        return fail(c, VSM_EINVAL, "bad geometry parameters (threshold %g, %d samples)", (double)g->max_sampson, g->hypotheses);
+    const bool resident = !offsets && !idx0 && !idx1;   // verify the lists of the last submission where they lie
+    if (!resident && (!offsets || (offsets[npairs] > 0 && (!idx0 || !idx1))))
+        return fail(c, VSM_EINVAL, "pass offsets, idx0 and idx1, or none of them");
+    if (resident && (c->inflight || c->last_npairs != npairs))
+        return fail(c, VSM_EINVAL, "no collected submission of %d pairs to verify", npairs);
+    HIPCHK(c, hipSetDevice(c->device));
+    in_offsets[0] = 0;
+    if (npairs == 0) return 0;
+    std::vector<int64_t> off_host;
+    if (resident) {
+        off_host.resize((size_t)npairs + 1);
+        HIPCHK(c, hipMemcpyAsync(off_host.data(), c->R().d_offsets.p, sizeof(int64_t) * (npairs + 1), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        offsets = off_host.data();
+    }
+    const int64_t total = offsets[npairs];
+    if (offsets[0] != 0 || total < 0) return fail(c, VSM_EINVAL, "offsets must start at 0 and ascend");
+    std::vector<GeomPair> gp(npairs);
+    int max_matches = 0;
+    for (int p = 0; p < npairs; ++p) {
+        const DescSet* A = get_set(c, xy_pairs[2 * p]);
+        const DescSet* B = get_set(c, xy_pairs[2 * p + 1]);
+        if (!A || !B || A->kind != SET_XY || B->kind != SET_XY)
+            return fail(c, VSM_EINVAL, "pair %d does not name two keypoint sets", p);
+        const int64_t n = offsets[p + 1] - offsets[p];
+        if (n < 0 || n > INT32_MAX) return fail(c, VSM_EINVAL, "offsets must ascend (pair %d)", p);
+        GeomPair& q = gp[p];
+        q.xy0 = static_cast<const float*>(A->frag);
+        q.xy1 = static_cast<const float*>(B->frag);
+        q.n0 = A->n; q.n1 = B->n;
+        q.n = (int32_t)n;
+        q.pad = 0;
+        q.off = offsets[p];
+        max_matches = std::max(max_matches, (int)n);
+    }
+    // one arena: pair records, match lists (unless resident), coordinates, per-pair results, slots, tight lists
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t tot = (size_t)std::max<int64_t>(total, 1);
+    const size_t b_gp = up(sizeof(GeomPair) * npairs), b_sp = up(sizeof(SiftPair) * npairs);
+    const size_t b_idx = resident ? 0 : up(tot * 4), b_co = up(tot * 16), b_F = up((size_t)npairs * 36);
+    const size_t b_cnt = up((size_t)npairs * 4), b_off = up(((size_t)npairs + 1) * 8), b_slot = up(tot * 4);
+    HIPCHK(c, c->d_geom.ensure(b_gp + b_sp + 2 * b_idx + b_co + 2 * b_F + 2 * b_cnt + b_off + 4 * b_slot));
+    char* w = c->d_geom.as<char>();
+    GeomPair* d_gp = reinterpret_cast<GeomPair*>(w); w += b_gp;
+    SiftPair* d_sp = reinterpret_cast<SiftPair*>(w); w += b_sp;
+    const int32_t* d_i0 = resident ? c->R().d_tight0.as<int32_t>() : reinterpret_cast<int32_t*>(w); w += b_idx;
+    const int32_t* d_i1 = resident ? c->R().d_tight1.as<int32_t>() : reinterpret_cast<int32_t*>(w); w += b_idx;
+    float4* d_co = reinterpret_cast<float4*>(w); w += b_co;
+    float* d_Fb = reinterpret_cast<float*>(w); w += b_F;
+    float* d_Fo = reinterpret_cast<float*>(w); w += b_F;
+    int32_t* d_bc = reinterpret_cast<int32_t*>(w); w += b_cnt;
+    int32_t* d_cnt = reinterpret_cast<int32_t*>(w); w += b_cnt;
+    int64_t* d_off = reinterpret_cast<int64_t*>(w); w += b_off;
+    int32_t* d_s0 = reinterpret_cast<int32_t*>(w); w += b_slot;
+    int32_t* d_s1 = reinterpret_cast<int32_t*>(w); w += b_slot;
+    int32_t* d_t0 = reinterpret_cast<int32_t*>(w); w += b_slot;
+    int32_t* d_t1 = reinterpret_cast<int32_t*>(w); w += b_slot;
+    HIPCHK(c, hipMemcpyAsync(d_gp, gp.data(), sizeof(GeomPair) * npairs, hipMemcpyHostToDevice, c->stream));
+    if (!resident && total > 0) {
+        HIPCHK(c, hipMemcpyAsync(const_cast<int32_t*>(d_i0), idx0, (size_t)total * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(const_cast<int32_t*>(d_i1), idx1, (size_t)total * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    GeomRule rule;
+    rule.max_sampson = g->max_sampson;
+    rule.hypotheses = g->hypotheses > 0 ? g->hypotheses : 256;
+    rule.seed = g->seed;
+    rule.min_inliers = g->min_inliers;
+    c->R().ev_valid = false;
+    c->timing_slot = c->rs;
+    if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
+    launch_geom_verify(d_gp, npairs, max_matches, d_i0, d_i1, rule, d_co, d_Fb, d_bc, d_Fo, d_cnt, d_s0, d_s1, d_sp, c->stream);
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
+        c->R().ev_valid = true;
+    }
+    launch_pack(d_sp, npairs, d_cnt, d_off, d_s0, d_s1, d_t0, d_t1, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(in_offsets, d_off, sizeof(int64_t) * (npairs + 1), hipMemcpyDeviceToHost, c->stream));
+    if (F) HIPCHK(c, hipMemcpyAsync(F, d_Fo, (size_t)npairs * 36, hipMemcpyDeviceToHost, c->stream));
+    if (nf) HIPCHK(c, hipMemcpyAsync(nf, d_cnt, (size_t)npairs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the pair records and lists above are host memory of this call
+    const long long got = in_offsets[npairs];
+    if (got > cap) return fail(c, VSM_ECAP, "%lld inlier matches do not fit a buffer of %lld", got, cap);
+    if (got > 0) {
+        if (in_idx0) HIPCHK(c, hipMemcpyAsync(in_idx0, d_t0, (size_t)got * 4, hipMemcpyDeviceToHost, c->stream));
+        if (in_idx1) HIPCHK(c, hipMemcpyAsync(in_idx1, d_t1, (size_t)got * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return got;
 }
 
 extern "C" int vsm_last_submission_pairs(const vsm_ctx* c) { return c ? c->slots[c->timing_slot].query_pairs : VSM_EINVAL; }

@@ -165,6 +165,27 @@ void launch_sift_verify(const SiftPair* pairs, int npairs, SiftItem* vitems, int
 void launch_sift_confirm(const SiftPair* pairs, int npairs, SiftCandidates cand, int mutual,
                          SiftOutputs out, hipStream_t s);
 // counts[npairs] -> offsets[npairs+1] (exclusive scan), then slots -> tight arrays
+// ---- geometric verification of putative matches -----------------------------------------
+struct GeomPair {
+    const float* xy0;   // keypoints of image 0: n0 x (x, y)
+    const float* xy1;
+    int32_t n0, n1;
+    int32_t n;          // putative matches of the pair
+    int32_t pad;
+    int64_t off;        // first match of the pair in the match arrays
+};
+struct GeomRule {
+    float max_sampson;   // inlier threshold on the Sampson distance, pixels
+    int hypotheses;      // samples per pair
+    unsigned seed;
+    int min_inliers;     // pairs with fewer inliers report none
+};
+size_t geom_lds_bytes();
+void launch_geom_verify(const GeomPair* pairs, int npairs, int max_matches, const int32_t* idx0, const int32_t* idx1,
+                        const GeomRule& rule, float4* coords, float* Fbest, int32_t* best_count,
+                        float* Fout, int32_t* counts, int32_t* slot_i0, int32_t* slot_i1, SiftPair* pack_pairs,
+                        hipStream_t s);
+
 void launch_pack(const SiftPair* pairs, int npairs, const int32_t* counts, int64_t* offsets,
                  const int32_t* slot_i0, const int32_t* slot_i1,
                  int32_t* tight_i0, int32_t* tight_i1, hipStream_t s);

@@ -209,3 +209,34 @@ def mutual_nn_match(matcher, desc0, desc1, match_threshold=0.2, descriptor_dim=N
         "matching_scores0": mscores0,
         "matching_scores1": mscores1,
     }
+
+
+def write_fmatch(image1, image2, idx1, idx2, F):
+    """MatchFile::WriteFMatch (MatchFile.cpp:596-605): geometry and inlier lists into both images' records."""
+    idx1 = np.ascontiguousarray(idx1, np.int32)
+    idx2 = np.ascontiguousarray(idx2, np.int32)
+    F = np.ascontiguousarray(F, np.float32).reshape(9)
+    rc = B.lib().vsm_mat_write_fmatch(_b(image1), _b(image2), len(idx1), B._ptr(idx1), B._ptr(idx2), B._ptr(F))
+    if rc < 0:
+        raise IOError("vsm_mat_write_fmatch failed (%d)" % rc)
+    return rc
+
+
+def _get_imatch(fn, image, other, fc_other):
+    import ctypes as C
+    F = np.zeros((3, 3), np.float32)
+    nf = C.c_int(0)
+    cap = max(int(fc_other), 1)
+    r0, r1 = np.empty(cap, np.int32), np.empty(cap, np.int32)
+    nm = fn(_b(image), _b(other), int(fc_other), B._ptr(F), C.byref(nf), B._ptr(r0), B._ptr(r1), cap)
+    return nm, F, r0[:nf.value], r1[:nf.value]
+
+
+def get_imatch(image, other, fc_other):
+    """MatchFile::GetIMatch (MatchFile.cpp:961-1021): (NM, F, inliers[0], inliers[1])."""
+    return _get_imatch(B.lib().vsm_mat_get_imatch, image, other, fc_other)
+
+
+def get_imatch_r(image, other, fc_other):
+    """MatchFile::GetIMatchR (MatchFile.cpp:1025-1084)."""
+    return _get_imatch(B.lib().vsm_mat_get_imatch_r, image, other, fc_other)

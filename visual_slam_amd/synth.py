@@ -46,3 +46,39 @@ def superpoint_pair(n0, n1, dim, seed, planted=0.25, sigma=0.05):
         pert /= np.linalg.norm(pert, axis=1, keepdims=True).astype(np.float32)
         b[dst] = pert.astype(np.float32)
     return a, b
+
+
+def two_view(n, seed, inlier_fraction=0.6, noise=0.5, width=1600.0, height=1200.0):
+    """Keypoints of two views of a random 3-D scene and n putative matches, the first
+    round(inlier_fraction * n) of them true correspondences (pixel noise `noise`), the rest random
+    pairings, then shuffled.  Returns (xy0 [n, 2], xy1 [n, 2], idx0, idx1, is_true, F) with
+    x1^T F x0 = 0 for the true ones."""
+    rng = np.random.default_rng(seed)
+    f = 1200.0
+    K = np.array([[f, 0, width / 2], [0, f, height / 2], [0, 0, 1.0]])
+    ang = rng.uniform(-0.25, 0.25, 3)
+    cx, cy, cz = np.cos(ang)
+    sx, sy, sz = np.sin(ang)
+    R = (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1.0]]) @ np.array([[cy, 0, sy], [0, 1.0, 0], [-sy, 0, cy]])
+         @ np.array([[1.0, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+    t = rng.uniform(-1.0, 1.0, 3)
+    t[2] *= 0.3
+    X = np.stack([rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(4, 12, n)], 1)
+    p0 = (K @ X.T).T
+    p1 = (K @ (R @ X.T + t[:, None])).T
+    xy0 = p0[:, :2] / p0[:, 2:3]
+    xy1 = p1[:, :2] / p1[:, 2:3]
+    ntrue = int(round(inlier_fraction * n))
+    xy0 = xy0 + noise * rng.standard_normal(xy0.shape)
+    xy1 = xy1 + noise * rng.standard_normal(xy1.shape)
+    idx0 = np.arange(n)
+    idx1 = np.arange(n)
+    idx1[ntrue:] = rng.permutation(n)[: n - ntrue]          # wrong partners for the rest
+    is_true = np.arange(n) < ntrue
+    is_true[ntrue:] = idx1[ntrue:] == idx0[ntrue:]
+    order = rng.permutation(n)
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Kinv = np.linalg.inv(K)
+    F = Kinv.T @ tx @ R @ Kinv
+    return (xy0.astype(np.float32), xy1.astype(np.float32), idx0[order].astype(np.int32),
+            idx1[order].astype(np.int32), is_true[order], F / np.linalg.norm(F))
