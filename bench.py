@@ -62,7 +62,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sift_exhaustive",
-                    choices=["sift_exhaustive", "superpoint_pair", "superpoint_pairs", "sift_large_pair", "db_query"])
+                    choices=["sift_exhaustive", "superpoint_pair", "superpoint_pairs", "sift_large_pair", "db_query",
+                             "geom_verify"])
     ap.add_argument("--images", type=int, default=1000)
     ap.add_argument("--features", type=int, default=8192)
     ap.add_argument("--pairs-per-step", type=int, default=2048)
@@ -420,6 +421,72 @@ def run_sift_large_pair(args, torch, dist, world, rank):
     return out
 
 
+def run_geom_verify(args, torch, dist, world, rank):
+    """Geometric verification of the putative matches of 4096 image pairs per step (768 matches per pair,
+    about what the exhaustive SIFT workload leaves; 256 RANSAC samples per pair).  The pair list shards
+    like the matching does: no data-path collective."""
+    import visual_slam_amd as vsm
+    from visual_slam_amd import synth
+
+    npairs, nmatch, hyp, nscene = 4096, 768, 256, 32
+    m = vsm.Matcher(torch.cuda.current_device())
+    scenes = []
+    for k in range(nscene):
+        xy0, xy1, i0, i1, _, _ = synth.two_view(nmatch, seed=1000 * rank + k, inlier_fraction=0.7, noise=0.5)
+        scenes.append((m.upload_xy(xy0), m.upload_xy(xy1), i0, i1, xy0, xy1))
+    xp = np.asarray([[scenes[p % nscene][0], scenes[p % nscene][1]] for p in range(npairs)], np.int32)
+    off = np.arange(npairs + 1, dtype=np.int64) * nmatch
+    i0 = np.concatenate([scenes[p % nscene][2] for p in range(npairs)])
+    i1 = np.concatenate([scenes[p % nscene][3] for p in range(npairs)])
+    m.set_timing(True)
+
+    def step():
+        return m.verify_matches(xp, off, i0, i1, max_sampson=2.0, hypotheses=hyp, seed=7)
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(torch, dist, world)
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        F, nf, in_off, g0, g1 = step()
+        kernel_ms.append(m.last_kernel_ms())
+    barrier_sync(torch, dist, world)
+    dt = max_over_ranks(torch, dist, world, time.perf_counter() - t0)
+    kms = float(np.mean(kernel_ms))
+    tests = float(npairs) * hyp * nmatch           # Sampson tests of one step
+    flops = 33.0 * tests                           # 18 multiplies + 15 adds per test (15 of the pairs fused)
+    achieved = flops / (kms * 1e-3) / 1e12
+    out = {
+        "metric": "image pairs verified/sec", "value": world * args.steps * npairs / dt, "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "fundamental-matrix RANSAC, %d pairs x %d matches, %d samples per pair per step"
+                               % (npairs, nmatch, hyp),
+                   "parallelism": "pair list sharded x%d" % world, "inliers_per_pair": float(np.mean(nf))},
+        "roofline": {"bound": "valu", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "geom_ransac_kernel",
+                     "kernel_ms": kms,
+                     "note": "f32 vector peak; kernel_ms brackets gather + RANSAC + final scoring; the eight-point "
+                             "solves (f64, LDS-resident) are not counted as work"},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+        import oracle_lib as orc
+        t1 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            sc = scenes[done % nscene]
+            orc.geom_pair(sc[4], sc[5], sc[2], sc[3], max_sampson=2.0, hypotheses=hyp, seed=7, pair_pos=done)
+            done += 1
+        el = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": done / el, "unit": "pairs/s", "cores": orc.THREADS, "kind": "port",
+                               "sample": "oracle RANSAC on %d pairs of the same shape, %.1f s" % (done, el)}
+    m.close()
+    return out
+
+
 def run_db_query(args, torch, dist, world, rank):
     """16384 float-256 queries against a 1M-row database cut into `world` contiguous slices;
     every rank searches its slice, the per-slice 2-NN lists are all-gathered and merged."""
@@ -493,7 +560,7 @@ def main():
     torch, dist, world, rank, local = dist_setup(args)
     fn = {"sift_exhaustive": run_sift_exhaustive, "superpoint_pair": run_superpoint_pair,
           "superpoint_pairs": run_superpoint_pairs,
-          "sift_large_pair": run_sift_large_pair, "db_query": run_db_query}[args.workload]
+          "sift_large_pair": run_sift_large_pair, "db_query": run_db_query, "geom_verify": run_geom_verify}[args.workload]
     out = fn(args, torch, dist, world, rank)
     if rank == 0:
         print(json.dumps(out))

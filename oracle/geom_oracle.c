@@ -10,7 +10,8 @@
  *   sample h of the pair at position p of a call: eight distinct matches from splitmix64 counters;
  *   Hartley normalisation, 8 x 9 system of x1^T F x0 = 0, Gaussian elimination with complete
  *   pivoting, free unknown 1, unit norm, de-normalisation, unit Frobenius norm (double);
- *   inliers by e^2 < t^2 (a0^2 + a1^2 + b0^2 + b1^2) in float; most inliers wins, lowest h on ties;
+ *   inliers by e^2 < t^2 (a0^2 + a1^2 + b0^2 + b1^2) in float with explicit fused multiply-adds;
+ *   most inliers wins, lowest h on ties;
  *   the winner projected to rank 2 (Jacobi on F^T F), inliers re-scored, listed in match order. */
 #include <math.h>
 #include <stdint.h>
@@ -27,13 +28,13 @@ static uint64_t splitmix64(uint64_t x)
 
 static int inlier(const float* F, const float* p, float t2)
 {
-    const float a0 = (F[0] * p[0] + F[1] * p[1]) + F[2];
-    const float a1 = (F[3] * p[0] + F[4] * p[1]) + F[5];
-    const float a2 = (F[6] * p[0] + F[7] * p[1]) + F[8];
-    const float b0 = (F[0] * p[2] + F[3] * p[3]) + F[6];
-    const float b1 = (F[1] * p[2] + F[4] * p[3]) + F[7];
-    const float e = (p[2] * a0 + p[3] * a1) + a2;
-    const float den = ((a0 * a0 + a1 * a1) + b0 * b0) + b1 * b1;
+    const float a0 = fmaf(F[0], p[0], fmaf(F[1], p[1], F[2]));
+    const float a1 = fmaf(F[3], p[0], fmaf(F[4], p[1], F[5]));
+    const float a2 = fmaf(F[6], p[0], fmaf(F[7], p[1], F[8]));
+    const float b0 = fmaf(F[0], p[2], fmaf(F[3], p[3], F[6]));
+    const float b1 = fmaf(F[1], p[2], fmaf(F[4], p[3], F[7]));
+    const float e = fmaf(p[2], a0, fmaf(p[3], a1, a2));
+    const float den = fmaf(b1, b1, fmaf(b0, b0, fmaf(a1, a1, a0 * a0)));
     return e * e < t2 * den;
 }
 

@@ -11,14 +11,20 @@
 //                        x1^T F x0 = 0, Gaussian elimination with complete pivoting, free variable 1,
 //                        back substitution, unit norm, de-normalisation, unit Frobenius norm (f64)
 //   score              : F rounded to f32; a match is an inlier when e^2 < t^2 * (a0^2 + a1^2 + b0^2 + b1^2)
-//                        with a = F x0, b = F^T x1, e = x1 . a (f32, no contraction)
+//                        with a = F x0, b = F^T x1, e = x1 . a (f32, every multiply-add one fused operation
+//                        in the order written in sampson_inlier)
 //   winner             : most inliers, lowest sample index among equals
 //   finish             : rank 2 enforced on the winner (f64 Jacobi eigenvectors of F^T F, the direction
 //                        of the smallest eigenvalue projected out), unit Frobenius norm, rounded to
 //                        f32, inliers re-scored with that matrix and listed in match order
 //
-// Every operation is an IEEE add, multiply, divide, square root or compare in a fixed order: results
-// do not depend on the grid, and the file is compiled without floating-point contraction.
+// Every operation is an IEEE add, multiply, fused multiply-add (only where written as one), divide,
+// square root or compare in a fixed order: results do not depend on the grid, and the file is compiled
+// without floating-point contraction.
+//
+// Kernels: gather (match coordinates), solve (one sample per thread; the 8 x 9 systems sit in LDS, which
+// limits that kernel to one wave per SIMD, so it does nothing else), score (one sample per thread, all
+// matches of the pair, workgroup-wide choice of the winner), emit (rank 2, final inlier list).
 #include <hip/hip_runtime.h>
 
 #include "vsm_internal.h"
@@ -60,13 +66,13 @@ __global__ void geom_gather_kernel(const GeomPair* __restrict__ pairs, int npair
 
 __device__ __forceinline__ bool sampson_inlier(const float (&F)[9], const float4 p, float t2)
 {
-    const float a0 = (F[0] * p.x + F[1] * p.y) + F[2];
-    const float a1 = (F[3] * p.x + F[4] * p.y) + F[5];
-    const float a2 = (F[6] * p.x + F[7] * p.y) + F[8];
-    const float b0 = (F[0] * p.z + F[3] * p.w) + F[6];
-    const float b1 = (F[1] * p.z + F[4] * p.w) + F[7];
-    const float e = (p.z * a0 + p.w * a1) + a2;
-    const float den = ((a0 * a0 + a1 * a1) + b0 * b0) + b1 * b1;
+    const float a0 = __builtin_fmaf(F[0], p.x, __builtin_fmaf(F[1], p.y, F[2]));
+    const float a1 = __builtin_fmaf(F[3], p.x, __builtin_fmaf(F[4], p.y, F[5]));
+    const float a2 = __builtin_fmaf(F[6], p.x, __builtin_fmaf(F[7], p.y, F[8]));
+    const float b0 = __builtin_fmaf(F[0], p.z, __builtin_fmaf(F[3], p.w, F[6]));
+    const float b1 = __builtin_fmaf(F[1], p.z, __builtin_fmaf(F[4], p.w, F[7]));
+    const float e = __builtin_fmaf(p.z, a0, __builtin_fmaf(p.w, a1, a2));
+    const float den = __builtin_fmaf(b1, b1, __builtin_fmaf(b0, b0, __builtin_fmaf(a1, a1, a0 * a0)));
     return e * e < t2 * den;
 }
 
@@ -172,63 +178,83 @@ __device__ bool solve_sample(double* __restrict__ A, const float4 (&pt)[8], floa
     return true;
 }
 
-// one workgroup per image pair; thread t runs samples t, t + 128, ...
+// One sample per thread: grid (ceil(samples / 128), pairs).  An unusable sample (fewer than eight
+// matches, repeated draws, degenerate points) leaves a NaN in the first element of its matrix.
 __global__ __launch_bounds__(kGeomThreads)
-void geom_ransac_kernel(const GeomPair* __restrict__ pairs, const float4* __restrict__ coords,
-                        GeomRule rule, float* __restrict__ Fbest, int32_t* __restrict__ best_count)
+void geom_solve_kernel(const GeomPair* __restrict__ pairs, const float4* __restrict__ coords,
+                       GeomRule rule, float* __restrict__ Fh)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* A = reinterpret_cast<double*>(smem);
-    __shared__ unsigned long long s_key[kGeomThreads];
+    const GeomPair gp = pairs[blockIdx.y];
+    const int h = blockIdx.x * kGeomThreads + threadIdx.x;
+    if (h >= rule.hypotheses) return;
+    float* out = Fh + ((size_t)blockIdx.y * rule.hypotheses + h) * 9;
+    const float4* __restrict__ pts = coords + gp.off;
+    const int n = gp.n;
+    float F[9];
+    bool ok = n >= 8;
+    if (ok) {
+        const unsigned long long base = splitmix64(((unsigned long long)rule.seed << 32) ^ (unsigned long long)(unsigned)blockIdx.y);
+        int pick[8];
+        int got = 0;
+        for (int ctr = 0; ctr < 64 && got < 8; ++ctr) {
+            const unsigned long long r = splitmix64(base + ((unsigned long long)h << 8) + (unsigned long long)ctr);
+            const int idx = (int)(((r >> 32) * (unsigned long long)n) >> 32);
+            bool dup = false;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dup = dup || (k < got && pick[k] == idx);
+            if (!dup) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k == got) pick[k] = idx;
+                ++got;
+            }
+        }
+        ok = got == 8;
+        if (ok) {
+            float4 pt[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pt[k] = pts[pick[k]];
+            ok = solve_sample(A, pt, F);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) out[j] = ok ? F[j] : __builtin_nanf("");
+}
+
+// one workgroup per image pair; thread t scores samples t, t + 256, ... against all matches
+constexpr int kGeomScoreThreads = 256;
+__global__ __launch_bounds__(kGeomScoreThreads)
+void geom_score_kernel(const GeomPair* __restrict__ pairs, const float4* __restrict__ coords,
+                       GeomRule rule, const float* __restrict__ Fh, float* __restrict__ Fbest,
+                       int32_t* __restrict__ best_count)
+{
+    __shared__ unsigned long long s_key[kGeomScoreThreads];
     const GeomPair gp = pairs[blockIdx.x];
     const int t = threadIdx.x;
     const float4* __restrict__ pts = coords + gp.off;
     const int n = gp.n;
     const float t2 = rule.max_sampson * rule.max_sampson;
-    const unsigned long long base = splitmix64(((unsigned long long)rule.seed << 32) ^ (unsigned long long)(unsigned)blockIdx.x);
-
     int mycount = -1, myh = 0;
-    float myF[9];
+    for (int h = t; h < rule.hypotheses; h += kGeomScoreThreads) {
+        const float* src = Fh + ((size_t)blockIdx.x * rule.hypotheses + h) * 9;
+        float F[9];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) myF[j] = 0.0f;
-    if (n >= 8) {
-        for (int h = t; h < rule.hypotheses; h += kGeomThreads) {
-            // eight distinct matches
-            int pick[8];
-            int got = 0;
-            for (int ctr = 0; ctr < 64 && got < 8; ++ctr) {
-                const unsigned long long r = splitmix64(base + ((unsigned long long)h << 8) + (unsigned long long)ctr);
-                const int idx = (int)(((r >> 32) * (unsigned long long)n) >> 32);
-                bool dup = false;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) dup = dup || (k < got && pick[k] == idx);
-                if (!dup) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if (k == got) pick[k] = idx;
-                    ++got;
-                }
-            }
-            if (got < 8) continue;
-            float4 pt[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) pt[k] = pts[pick[k]];
-            float F[9];
-            if (!solve_sample(A, pt, F)) continue;
-            int cnt = 0;
-            for (int m = 0; m < n; ++m) cnt += sampson_inlier(F, pts[m], t2) ? 1 : 0;
-            if (cnt > mycount) {   // samples come in ascending order: the first of equals stays
-                mycount = cnt;
-                myh = h;
-#pragma unroll
-                for (int j = 0; j < 9; ++j) myF[j] = F[j];
-            }
+        for (int j = 0; j < 9; ++j) F[j] = src[j];
+        if (F[0] != F[0]) continue;   // unusable sample
+        int cnt = 0;
+        for (int m = 0; m < n; ++m) cnt += sampson_inlier(F, pts[m], t2) ? 1 : 0;
+        if (cnt > mycount) {   // samples come in ascending order: the first of equals stays
+            mycount = cnt;
+            myh = h;
         }
     }
     // most inliers, then lowest sample index
-    s_key[t] = mycount < 0 ? 0ull : (((unsigned long long)(unsigned)(mycount + 1)) << 32) | (unsigned)(0x7fffffff - myh);
+    const unsigned long long mine = mycount < 0 ? 0ull : (((unsigned long long)(unsigned)(mycount + 1)) << 32) | (unsigned)(0x7fffffff - myh);
+    s_key[t] = mine;
     __syncthreads();
-    for (int d = kGeomThreads / 2; d > 0; d >>= 1) {
+    for (int d = kGeomScoreThreads / 2; d > 0; d >>= 1) {
         if (t < d && s_key[t + d] > s_key[t]) s_key[t] = s_key[t + d];
         __syncthreads();
     }
@@ -240,10 +266,10 @@ void geom_ransac_kernel(const GeomPair* __restrict__ pairs, const float4* __rest
         }
         return;
     }
-    const unsigned long long mine = mycount < 0 ? 0ull : (((unsigned long long)(unsigned)(mycount + 1)) << 32) | (unsigned)(0x7fffffff - myh);
     if (mine == win) {   // exactly one thread: sample indices are distinct
         best_count[blockIdx.x] = mycount;
-        for (int j = 0; j < 9; ++j) Fbest[(size_t)blockIdx.x * 9 + j] = myF[j];
+        const float* src = Fh + ((size_t)blockIdx.x * rule.hypotheses + myh) * 9;
+        for (int j = 0; j < 9; ++j) Fbest[(size_t)blockIdx.x * 9 + j] = src[j];
     }
 }
 
@@ -368,7 +394,7 @@ __global__ void geom_pack_pairs_kernel(const GeomPair* __restrict__ gp, int npai
 size_t geom_lds_bytes() { return (size_t)72 * kGeomThreads * sizeof(double); }
 
 void launch_geom_verify(const GeomPair* pairs, int npairs, int max_matches, const int32_t* idx0, const int32_t* idx1,
-                        const GeomRule& rule, float4* coords, float* Fbest, int32_t* best_count,
+                        const GeomRule& rule, float4* coords, float* Fh, float* Fbest, int32_t* best_count,
                         float* Fout, int32_t* counts, int32_t* slot_i0, int32_t* slot_i1, SiftPair* pack_pairs,
                         hipStream_t s)
 {
@@ -377,12 +403,14 @@ void launch_geom_verify(const GeomPair* pairs, int npairs, int max_matches, cons
     hipLaunchKernelGGL(geom_gather_kernel, dim3(gx, npairs), dim3(256), 0, s, pairs, npairs, idx0, idx1, coords);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(geom_ransac_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(geom_solve_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom_lds_bytes());
         attr_set = true;
     }
-    hipLaunchKernelGGL(geom_ransac_kernel, dim3(npairs), dim3(kGeomThreads), geom_lds_bytes(), s,
-                       pairs, coords, rule, Fbest, best_count);
+    hipLaunchKernelGGL(geom_solve_kernel, dim3((rule.hypotheses + kGeomThreads - 1) / kGeomThreads, npairs),
+                       dim3(kGeomThreads), geom_lds_bytes(), s, pairs, coords, rule, Fh);
+    hipLaunchKernelGGL(geom_score_kernel, dim3(npairs), dim3(kGeomScoreThreads), 0, s,
+                       pairs, coords, rule, Fh, Fbest, best_count);
     hipLaunchKernelGGL(geom_emit_kernel, dim3(npairs), dim3(kGeomEmitThreads), 0, s,
                        pairs, coords, idx0, idx1, rule, Fbest, best_count, Fout, counts, slot_i0, slot_i1);
     hipLaunchKernelGGL(geom_pack_pairs_kernel, dim3((npairs + 255) / 256), dim3(256), 0, s, pairs, npairs, pack_pairs);

@@ -1349,7 +1349,7 @@ extern "C" long long vsm_verify_matches(vsm_ctx* c, const int32_t* xy_pairs, int
     if (!c) return VSM_EINVAL;
     if (npairs < 0 || (npairs > 0 && !xy_pairs) || !g || !in_offsets) return fail(c, VSM_EINVAL, "bad argument");
     if (npairs > 65535) return fail(c, VSM_EINVAL, "%d pairs in one call (limit 65535)", npairs);
-    if (!(g->max_sampson > 0.0f) || g->hypotheses < 0 || g->hypotheses > (1 << 20))
+    if (!(g->max_sampson > 0.0f) || g->hypotheses < 0 || g->hypotheses > 65536)
         return fail(c, VSM_EINVAL, "bad geometry parameters (threshold %g, %d samples)", (double)g->max_sampson, g->hypotheses);
     const bool resident = !offsets && !idx0 && !idx1;   // verify the lists of the last submission where they lie
     if (!resident && (!offsets || (offsets[npairs] > 0 && (!idx0 || !idx1))))
@@ -1392,13 +1392,16 @@ extern "C" long long vsm_verify_matches(vsm_ctx* c, const int32_t* xy_pairs, int
     const size_t b_gp = up(sizeof(GeomPair) * npairs), b_sp = up(sizeof(SiftPair) * npairs);
     const size_t b_idx = resident ? 0 : up(tot * 4), b_co = up(tot * 16), b_F = up((size_t)npairs * 36);
     const size_t b_cnt = up((size_t)npairs * 4), b_off = up(((size_t)npairs + 1) * 8), b_slot = up(tot * 4);
-    HIPCHK(c, c->d_geom.ensure(b_gp + b_sp + 2 * b_idx + b_co + 2 * b_F + 2 * b_cnt + b_off + 4 * b_slot));
+    const int nhyp = g->hypotheses > 0 ? g->hypotheses : 256;
+    const size_t b_Fh = up((size_t)npairs * nhyp * 36);
+    HIPCHK(c, c->d_geom.ensure(b_gp + b_sp + 2 * b_idx + b_co + b_Fh + 2 * b_F + 2 * b_cnt + b_off + 4 * b_slot));
     char* w = c->d_geom.as<char>();
     GeomPair* d_gp = reinterpret_cast<GeomPair*>(w); w += b_gp;
     SiftPair* d_sp = reinterpret_cast<SiftPair*>(w); w += b_sp;
     const int32_t* d_i0 = resident ? c->R().d_tight0.as<int32_t>() : reinterpret_cast<int32_t*>(w); w += b_idx;
     const int32_t* d_i1 = resident ? c->R().d_tight1.as<int32_t>() : reinterpret_cast<int32_t*>(w); w += b_idx;
     float4* d_co = reinterpret_cast<float4*>(w); w += b_co;
+    float* d_Fh = reinterpret_cast<float*>(w); w += b_Fh;
     float* d_Fb = reinterpret_cast<float*>(w); w += b_F;
     float* d_Fo = reinterpret_cast<float*>(w); w += b_F;
     int32_t* d_bc = reinterpret_cast<int32_t*>(w); w += b_cnt;
@@ -1415,13 +1418,13 @@ extern "C" long long vsm_verify_matches(vsm_ctx* c, const int32_t* xy_pairs, int
     }
     GeomRule rule;
     rule.max_sampson = g->max_sampson;
-    rule.hypotheses = g->hypotheses > 0 ? g->hypotheses : 256;
+    rule.hypotheses = nhyp;
     rule.seed = g->seed;
     rule.min_inliers = g->min_inliers;
     c->R().ev_valid = false;
     c->timing_slot = c->rs;
     if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
-    launch_geom_verify(d_gp, npairs, max_matches, d_i0, d_i1, rule, d_co, d_Fb, d_bc, d_Fo, d_cnt, d_s0, d_s1, d_sp, c->stream);
+    launch_geom_verify(d_gp, npairs, max_matches, d_i0, d_i1, rule, d_co, d_Fh, d_Fb, d_bc, d_Fo, d_cnt, d_s0, d_s1, d_sp, c->stream);
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
         c->R().ev_valid = true;
