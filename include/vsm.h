@@ -176,7 +176,8 @@ typedef struct vsm_geom_params {
 int vsm_upload_xy(vsm_ctx* ctx, const float* xy, int n);
 /* xy_pairs[npairs][2]: keypoint sets of each pair's two images.  The putative matches come as
  * offsets[npairs + 1] / idx0 / idx1 (the layout vsm_match_pairs returns), or, with all three NULL, are
- * the lists of the last collected submission of npairs pairs, read where they lie on the device.
+ * the lists of the last collected submission of npairs pairs, read where they lie on the device (they
+ * stay there until the second submission after it; one later submission may be in flight).
  * Out: F[npairs][9] (row-major, may be NULL), nf[npairs] (may be NULL), in_offsets[npairs + 1] and
  * the inlier matches of all pairs in in_idx0 / in_idx1 (feature indices, in match order).
  * Returns the total number of inlier matches, or VSM_ECAP with in_offsets filled. */
@@ -260,6 +261,9 @@ int vsm_mat_write_fmatch(const char* image1, const char* image2, int nf, const i
                          const int32_t* idx2, const float* F);
 /* MatchFile::GetIMatch / GetIMatchR (MatchFile.cpp:961-1084): F[9], *nf and up to cap inlier pairs;
  * returns NM of the record (0 when absent or rejected by the reference's checks). */
+/* The same through a vsm_matwriter (directories cached; see vsm_mat_writer_open). */
+int vsm_mat_writer_put_fmatch(vsm_matwriter* w, const char* image1, const char* image2, int nf,
+                              const int32_t* idx1, const int32_t* idx2, const float* F);
 int vsm_mat_get_imatch(const char* image, const char* other, int fc_other, float* F, int* nf,
                        int32_t* row0, int32_t* row1, int cap);
 int vsm_mat_get_imatch_r(const char* image, const char* other, int fc_other, float* F, int* nf,

@@ -73,3 +73,50 @@ def test_sharded_runs_concatenate_to_the_unsharded_file(tmp_path):
     assert res.returncode == 0, res.stderr
     assert open(sharded, "rb").read() == open(whole, "rb").read()
     assert os.path.getsize(whole) > 1000
+
+
+def _read_records(path):
+    lines = open(path).read().split("\n")
+    recs = []
+    for k in range(0, len(lines) - 1, 3):
+        name0, name1, n = lines[k].split()
+        recs.append((name0, name1, np.array(lines[k + 1].split(), np.int32), np.array(lines[k + 2].split(), np.int32)))
+        assert len(recs[-1][2]) == int(n)
+    return recs
+
+
+def test_cli_verifies_matches_on_the_device(tmp_path):
+    """--verify: the inlier lists and matrices the driver writes (match txt and .mat inlier records) are
+    the ones the oracle derives from the putative lists of the same run."""
+    nimg, n, batch = 4, 500, 4
+    kps, dess = synth.multi_view(nimg, n, seed=31)
+    for i in range(nimg):
+        loc = np.zeros((n, 5), np.float32)
+        loc[:, :2] = kps[i]
+        loc[:, 3] = 1.0
+        host.write_sift(str(tmp_path / ("%d.sift" % i)), loc, dess[i])
+    out, inl = str(tmp_path / "matching.txt"), str(tmp_path / "inliers.txt")
+    cmd = [CLI, "--sift-dir", str(tmp_path), "--num", str(nimg), "--out", out, "--batch", str(batch), "--mat",
+           "--verify", "1.5", "--samples", "300", "--seed", "5", "--inlier-out", inl, "--min-inliers", "12"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    put, ver = _read_records(out), _read_records(inl)
+    assert len(put) == len(ver) == nimg * (nimg - 1) // 2
+    kept = 0
+    for k, ((a0, a1, p0, p1), (b0, b1, v0, v1)) in enumerate(zip(put, ver)):
+        assert (a0, a1) == (b0, b1)
+        ia, ib = int(a0.split(".")[0]), int(a1.split(".")[0])
+        F, o0, o1 = orc.geom_pair(kps[ia], kps[ib], p0, p1, max_sampson=1.5, hypotheses=300, seed=5, pair_pos=k % batch,
+                                  min_inliers=12)
+        np.testing.assert_array_equal(v0, o0)
+        np.testing.assert_array_equal(v1, o1)
+        nm, Fm, r0, r1 = host.get_imatch(str(tmp_path / str(ia)), str(tmp_path / str(ib)), n)
+        assert nm == len(p0)
+        np.testing.assert_array_equal(Fm, F)
+        np.testing.assert_array_equal(r0, o0)
+        np.testing.assert_array_equal(r1, o1)
+        g0, g1 = host.get_pmatch(str(tmp_path / str(ia)), str(tmp_path / str(ib)), n)   # putative lists intact
+        np.testing.assert_array_equal(g0, p0)
+        kept += len(o0)
+        assert len(p0) > 150 and len(o0) > 0.3 * len(p0)
+    assert "geometric verification: %d pairs" % len(put) in res.stderr and kept > 1000

@@ -102,6 +102,7 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_longlong]),
     "vsm_mat_write_fmatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsm_mat_writer_put_fmatch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsm_mat_get_imatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.POINTER(C.c_int),
                                      C.c_void_p, C.c_void_p, C.c_int]),
     "vsm_mat_get_imatch_r": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.POINTER(C.c_int),

@@ -840,12 +840,10 @@ namespace {
 // have room, which every record written by WritePMatch has (block = 184 + max(NM, 8) * 24 bytes against
 // 188 + (NM + NF) * 8 needed, NF <= NM); the reference's re-allocation branch (:690-719) moves the
 // directory entry without the putative lists and is not reproduced.
-int mat_put_inliers(const std::string& image, const std::string& other, bool reverse, int nf,
+int mat_put_inliers(MatFile& mf, const std::string& other, bool reverse, int nf,
                     const int32_t* row_a, const int32_t* row_b, const float* F)
 {
-    MatFile mf;
-    if (!mf.open(image, true)) return VSM_EIO;
-    const int idx = mf.find(relative_name(image, other));
+    const int idx = mf.find(relative_name(mf.image(), other));
     if (idx < 0) return 0;
     const MatRecLoc* loc = mf.rec(idx);
     int32_t nm = 0;
@@ -877,11 +875,28 @@ extern "C" int vsm_mat_write_fmatch(const char* image1, const char* image2, int 
 {
     if (!image1 || !image2 || !image1[0] || !image2[0] || nf < 0 || (nf > 0 && (!idx1 || !idx2 || !F))) return VSM_EINVAL;
     if (strlen(image1) + 5 > (size_t)kMaxPath || strlen(image2) + 5 > (size_t)kMaxPath) return VSM_EINVAL;
-    const int a = mat_put_inliers(image1, image2, false, nf, idx1, idx2, F);
+    MatFile m1, m2;
+    if (!m1.open(image1, true)) return VSM_EIO;
+    const int a = mat_put_inliers(m1, image2, false, nf, idx1, idx2, F);
     if (a < 0) return a;
-    const int b = mat_put_inliers(image2, image1, true, nf, idx1, idx2, F);
+    if (!m2.open(image2, true)) return VSM_EIO;
+    const int b = mat_put_inliers(m2, image1, true, nf, idx1, idx2, F);
     if (b < 0) return b;
     return a == 1 && b == 1 ? 1 : 0;
+}
+
+extern "C" int vsm_mat_writer_put_fmatch(vsm_matwriter* w, const char* image1, const char* image2, int nf,
+                                         const int32_t* idx1, const int32_t* idx2, const float* F)
+{
+    if (!w || !image1 || !image2 || !image1[0] || !image2[0] || nf < 0 || (nf > 0 && (!idx1 || !idx2 || !F))) return VSM_EINVAL;
+    if (w->failed) return VSM_EIO;
+    MatFile* a = w->get(image1);
+    int ra = a ? mat_put_inliers(*a, image2, false, nf, idx1, idx2, F) : VSM_EIO;
+    if (ra < 0) return ra;
+    MatFile* b = w->get(image2);
+    int rb = b ? mat_put_inliers(*b, image1, true, nf, idx1, idx2, F) : VSM_EIO;
+    if (rb < 0) return rb;
+    return ra == 1 && rb == 1 ? 1 : 0;
 }
 
 static int mat_get_inliers(const char* image, const char* other, int fc_other, bool reverse, float* F, int* nf,

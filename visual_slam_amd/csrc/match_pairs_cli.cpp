@@ -29,6 +29,11 @@ struct Options {
     std::vector<int32_t> discrete{7, 15};
     int ratio_num = 4, ratio_den = 5;
     long long max_dist = -1;
+    float verify = 0.0f;          // > 0: geometric verification, Sampson threshold in pixels
+    int samples = 256;
+    unsigned seed = 0;
+    int min_inliers = 0;
+    std::string inlier_out;       // match txt of the verified matches
 };
 
 void usage()
@@ -44,6 +49,10 @@ void usage()
             "  --max-dist D          keep matches with squared distance <= D\n"
             "  --no-mutual           skip the mutual-nearest-neighbour check\n"
             "  --mat                 also write <DIR>/<i>.mat putative-match records\n"
+            "  --verify PIXELS       geometric verification of every pair's matches (fundamental-matrix RANSAC,\n"
+            "                        Sampson-distance threshold); with --mat the inlier records are written too\n"
+            "  --samples N           RANSAC samples per pair (default 256); --seed S; --min-inliers K\n"
+            "  --inlier-out FILE     match txt of the verified matches (same format as --out)\n"
             "  --name-ext EXT        image-name suffix in the match txt (default .jpg)\n"
             "  --device N, --batch P (pairs per GPU submission, default 4096; two are in flight)\n"
             "  --shard R/W           match only the R-th of W contiguous slices of the pair list (one process\n"
@@ -84,6 +93,11 @@ bool parse(int argc, char** argv, Options& o)
         else if (a == "--max-dist") { if (!(v = next("--max-dist"))) return false; o.max_dist = atoll(v); }
         else if (a == "--no-mutual") o.mutual = false;
         else if (a == "--mat") o.write_mat = true;
+        else if (a == "--verify") { if (!(v = next("--verify"))) return false; o.verify = (float)atof(v); }
+        else if (a == "--samples") { if (!(v = next("--samples"))) return false; o.samples = atoi(v); }
+        else if (a == "--seed") { if (!(v = next("--seed"))) return false; o.seed = (unsigned)strtoul(v, nullptr, 10); }
+        else if (a == "--min-inliers") { if (!(v = next("--min-inliers"))) return false; o.min_inliers = atoi(v); }
+        else if (a == "--inlier-out") { if (!(v = next("--inlier-out"))) return false; o.inlier_out = v; }
         else if (a == "--name-ext") { if (!(v = next("--name-ext"))) return false; o.name_ext = v; }
         else if (a == "--device") { if (!(v = next("--device"))) return false; o.device = atoi(v); }
         else if (a == "--batch") { if (!(v = next("--batch"))) return false; o.batch = atoi(v); }
@@ -96,7 +110,11 @@ bool parse(int argc, char** argv, Options& o)
         }
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
     }
-    return !o.sift_dir.empty() && o.num > 0 && o.batch > 0;
+    if (!o.inlier_out.empty() && !(o.verify > 0.0f)) {
+        fprintf(stderr, "--inlier-out needs --verify\n");
+        return false;
+    }
+    return !o.sift_dir.empty() && o.num > 0 && o.batch > 0 && o.samples > 0;
 }
 
 }  // namespace
@@ -117,12 +135,14 @@ int main(int argc, char** argv)
 
     // ---- load and upload every image's descriptors once: files are read by a few threads, 256 at a
     // time, and uploaded in order by this one
-    std::vector<int> set_id(o.num, -1), count(o.num, 0);
+    std::vector<int> set_id(o.num, -1), count(o.num, 0), xy_id(o.num, -1);
+    const bool verify = o.verify > 0.0f;
     {
         const int kChunk = 256;
         const int nthreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
         std::vector<std::vector<uint8_t>> des(kChunk);
-        std::vector<int> np(kChunk), bad(kChunk);
+        std::vector<std::vector<float>> loc(kChunk);
+        std::vector<int> np(kChunk), bad(kChunk), nlocs(kChunk);
         for (int base = 0; base < o.num; base += kChunk) {
             const int m = std::min(kChunk, o.num - base);
             std::vector<std::thread> readers;
@@ -133,8 +153,11 @@ int main(int argc, char** argv)
                         int n = 0, nloc = 0;
                         if (!vsm_sift_read(path.c_str(), nullptr, nullptr, 0, &n, &nloc)) n = 0;  // unreadable or empty
                         des[k].resize((size_t)n * VSM_DESC_DIM_U8 + 1);
-                        bad[k] = n > 0 && !vsm_sift_read(path.c_str(), nullptr, des[k].data(), n, nullptr, nullptr);
+                        if (verify) loc[k].resize((size_t)n * std::max(nloc, 2) + 1);
+                        bad[k] = n > 0 && !vsm_sift_read(path.c_str(), verify ? loc[k].data() : nullptr, des[k].data(), n, nullptr, nullptr);
+                        if (verify && n > 0 && nloc < 2) bad[k] = 1;
                         np[k] = n;
+                        nlocs[k] = nloc;
                     }
                 });
             for (auto& r : readers) r.join();
@@ -149,6 +172,19 @@ int main(int argc, char** argv)
                 if (set_id[i] < 0) {
                     fprintf(stderr, "upload %d%s: %s\n", i, o.sift_ext.c_str(), vsm_last_error(ctx));
                     return 1;
+                }
+                if (verify) {
+                    // x, y are the first two columns of a location record
+                    std::vector<float> xy((size_t)np[k] * 2 + 1);
+                    for (int r = 0; r < np[k]; ++r) {
+                        xy[2 * r] = loc[k][(size_t)r * nlocs[k]];
+                        xy[2 * r + 1] = loc[k][(size_t)r * nlocs[k] + 1];
+                    }
+                    xy_id[i] = vsm_upload_xy(ctx, xy.data(), np[k]);
+                    if (xy_id[i] < 0) {
+                        fprintf(stderr, "upload keypoints %d: %s\n", i, vsm_last_error(ctx));
+                        return 1;
+                    }
                 }
             }
         }
@@ -184,6 +220,21 @@ int main(int argc, char** argv)
         fprintf(stderr, "cannot open %s\n", o.out.c_str());
         return 1;
     }
+    vsm_txtwriter* tw_in = nullptr;
+    if (!o.inlier_out.empty()) {
+        std::string path = o.inlier_out;
+        if (o.nshards > 1 && path != "/dev/null") path += ".part" + std::to_string(o.shard);
+        tw_in = vsm_matchtxt_open(path.c_str(), o.append ? 0 : 1);
+        if (!tw_in) {
+            fprintf(stderr, "cannot open %s\n", path.c_str());
+            return 1;
+        }
+    }
+    vsm_geom_params gprm{};
+    gprm.max_sampson = o.verify;
+    gprm.hypotheses = o.samples;
+    gprm.seed = o.seed;
+    gprm.min_inliers = o.min_inliers;
     vsm_params prm{};
     prm.ratio_num = o.ratio_num;
     prm.ratio_den = o.ratio_den;
@@ -199,6 +250,10 @@ int main(int argc, char** argv)
         int take = 0;
         std::vector<int32_t> idx0, idx1;
         std::vector<int64_t> off;
+        // geometric verification
+        std::vector<float> F;
+        std::vector<int32_t> nf, in0, in1;
+        std::vector<int64_t> in_off;
     } batches[2];
     std::mutex mu;
     std::condition_variable cv;
@@ -233,6 +288,22 @@ int main(int argc, char** argv)
                         write_error = "cannot write .mat for pair " + std::to_string(ia) + " " + std::to_string(ib);
                     }
                 }
+                if (verify && !write_failed) {
+                    const int nin = (int)(b.in_off[k + 1] - b.in_off[k]);
+                    const int32_t* q0 = b.in0.data() + b.in_off[k];
+                    const int32_t* q1 = b.in1.data() + b.in_off[k];
+                    if (tw_in && vsm_matchtxt_write(tw_in, n0.c_str(), n1.c_str(), q0, q1, nin, count[ia]) < 0) {
+                        write_failed = true;
+                        write_error = "write error on " + o.inlier_out;
+                    }
+                    if (o.write_mat && !write_failed) {
+                        const std::string p0 = o.sift_dir + "/" + std::to_string(ia), p1 = o.sift_dir + "/" + std::to_string(ib);
+                        if (vsm_mat_writer_put_fmatch(mw, p0.c_str(), p1.c_str(), nin, q0, q1, b.F.data() + (size_t)k * 9) < 0) {
+                            write_failed = true;
+                            write_error = "cannot write inlier record for pair " + std::to_string(ia) + " " + std::to_string(ib);
+                        }
+                    }
+                }
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -244,8 +315,8 @@ int main(int argc, char** argv)
 
     // GPU side: submission k + 1 is queued before the lists of submission k are collected, so the
     // device never waits for this thread or for the writer
-    std::vector<int32_t> ids;
-    long long total = 0;
+    std::vector<int32_t> ids, xy_ids;
+    long long total = 0, total_inliers = 0, pairs_with_geometry = 0;
     bool gpu_failed = false;
     const long long nbatches = (npairs + o.batch - 1) / o.batch;
     auto submit = [&](long long k) {
@@ -291,6 +362,28 @@ int main(int argc, char** argv)
             break;
         }
         total += got;
+        if (verify) {
+            // the lists just collected are still on the device: verify them there
+            xy_ids.resize((size_t)take * 2);
+            for (int q = 0; q < take; ++q) {
+                xy_ids[2 * q] = xy_id[pairs[2 * (lo + q)]];
+                xy_ids[2 * q + 1] = xy_id[pairs[2 * (lo + q) + 1]];
+            }
+            b.F.resize((size_t)take * 9);
+            b.nf.resize((size_t)take);
+            b.in_off.resize((size_t)take + 1);
+            b.in0.resize((size_t)got + 1);
+            b.in1.resize((size_t)got + 1);
+            const long long gin = vsm_verify_matches(ctx, xy_ids.data(), take, nullptr, nullptr, nullptr, &gprm, b.F.data(),
+                                                     b.nf.data(), b.in_off.data(), b.in0.data(), b.in1.data(), got);
+            if (gin < 0) {
+                fprintf(stderr, "vsm_verify_matches: %s\n", vsm_last_error(ctx));
+                gpu_failed = true;
+                break;
+            }
+            total_inliers += gin;
+            for (int q = 0; q < take; ++q) pairs_with_geometry += b.nf[q] > 0;
+        }
         {
             std::lock_guard<std::mutex> lk(mu);
             filled[cur] = 1;
@@ -317,6 +410,13 @@ int main(int argc, char** argv)
         fprintf(stderr, "write error on %s\n", o.out.c_str());
         return 1;
     }
+    if (tw_in && vsm_matchtxt_close(tw_in) != VSM_OK) {
+        fprintf(stderr, "write error on %s\n", o.inlier_out.c_str());
+        return 1;
+    }
+    if (verify)
+        fprintf(stderr, "geometric verification: %lld pairs with a fundamental matrix, %lld inlier matches\n",
+                pairs_with_geometry, total_inliers);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     fprintf(stderr, "%d images, %lld pairs, %lld matches, %.3f s (%.0f pairs/s); reading + upload %.3f s, matching + writing %.3f s\n",
             o.num, npairs, total, secs, npairs / secs, load_secs, secs - load_secs);

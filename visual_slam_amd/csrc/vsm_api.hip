@@ -115,6 +115,7 @@ struct vsm_ctx {
     // last device-resident result
     int last_npairs = 0;
     long long last_total = 0;
+    int last_slot = 0;     // result slot that holds those lists
     // timing
     int timing = 0;
     int timing_slot = 0;   // slot whose brackets vsm_last_kernel_ms / vsm_last_verify_ms read
@@ -1005,6 +1006,7 @@ extern "C" long long vsm_match_pairs_device(vsm_ctx* c, const int32_t* pairs, in
             if (got < 0) return got;
             c->last_npairs = npairs;
             c->last_total = got;
+            c->last_slot = c->rs;
             return got;
         }
     } else {
@@ -1020,6 +1022,7 @@ extern "C" long long vsm_match_pairs_device(vsm_ctx* c, const int32_t* pairs, in
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->last_npairs = npairs;
     c->last_total = *tot;
+    c->last_slot = c->rs;
     return *tot;
 }
 
@@ -1123,6 +1126,7 @@ extern "C" int vsm_submit_pairs(vsm_ctx* c, const int32_t* pairs, int npairs, co
     const int slot = (c->inflight_head + c->inflight) & 1;
     const int timing_slot_before = c->timing_slot;
     c->rs = slot;
+    if (slot == c->last_slot) c->last_npairs = -1;   // the lists of the last collected submission are about to be overwritten
     const DescSet* first = npairs > 0 ? get_set(c, pairs[0]) : nullptr;
     bool on_host = false;
     if (first && first->kind == SET_F32) {
@@ -1172,6 +1176,7 @@ extern "C" long long vsm_collect_matches(vsm_ctx* c, int64_t* offsets, int32_t* 
     const long long got = off[npairs];
     c->last_npairs = npairs;
     c->last_total = got;
+    c->last_slot = slot;
     if (got > cap) return fail(c, VSM_ECAP, "%lld matches do not fit a buffer of %lld", got, cap);
     if (got > 0) {
         if (idx0) HIPCHK(c, hipMemcpyAsync(idx0, R.d_tight0.p, sizeof(int32_t) * got, hipMemcpyDeviceToHost, c->copy_stream));
@@ -1354,16 +1359,17 @@ extern "C" long long vsm_verify_matches(vsm_ctx* c, const int32_t* xy_pairs, int
     const bool resident = !offsets && !idx0 && !idx1;   // verify the lists of the last submission where they lie
     if (!resident && (!offsets || (offsets[npairs] > 0 && (!idx0 || !idx1))))
         return fail(c, VSM_EINVAL, "pass offsets, idx0 and idx1, or none of them");
-    if (resident && (c->inflight || c->last_npairs != npairs))
-        return fail(c, VSM_EINVAL, "no collected submission of %d pairs to verify", npairs);
+    // (one more submission may be in flight: it uses the other result slot, and this call queues behind it)
+    if (resident && c->last_npairs != npairs)
+        return fail(c, VSM_EINVAL, "no collected submission of %d pairs whose lists are still on the device", npairs);
     HIPCHK(c, hipSetDevice(c->device));
     in_offsets[0] = 0;
     if (npairs == 0) return 0;
     std::vector<int64_t> off_host;
     if (resident) {
         off_host.resize((size_t)npairs + 1);
-        HIPCHK(c, hipMemcpyAsync(off_host.data(), c->R().d_offsets.p, sizeof(int64_t) * (npairs + 1), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpyAsync(off_host.data(), c->slots[c->last_slot].d_offsets.p, sizeof(int64_t) * (npairs + 1), hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
         offsets = off_host.data();
     }
     const int64_t total = offsets[npairs];
@@ -1398,8 +1404,8 @@ extern "C" long long vsm_verify_matches(vsm_ctx* c, const int32_t* xy_pairs, int
     char* w = c->d_geom.as<char>();
     GeomPair* d_gp = reinterpret_cast<GeomPair*>(w); w += b_gp;
     SiftPair* d_sp = reinterpret_cast<SiftPair*>(w); w += b_sp;
-    const int32_t* d_i0 = resident ? c->R().d_tight0.as<int32_t>() : reinterpret_cast<int32_t*>(w); w += b_idx;
-    const int32_t* d_i1 = resident ? c->R().d_tight1.as<int32_t>() : reinterpret_cast<int32_t*>(w); w += b_idx;
+    const int32_t* d_i0 = resident ? c->slots[c->last_slot].d_tight0.as<int32_t>() : reinterpret_cast<int32_t*>(w); w += b_idx;
+    const int32_t* d_i1 = resident ? c->slots[c->last_slot].d_tight1.as<int32_t>() : reinterpret_cast<int32_t*>(w); w += b_idx;
     float4* d_co = reinterpret_cast<float4*>(w); w += b_co;
     float* d_Fh = reinterpret_cast<float*>(w); w += b_Fh;
     float* d_Fb = reinterpret_cast<float*>(w); w += b_F;
@@ -1421,11 +1427,14 @@ extern "C" long long vsm_verify_matches(vsm_ctx* c, const int32_t* xy_pairs, int
     rule.hypotheses = nhyp;
     rule.seed = g->seed;
     rule.min_inliers = g->min_inliers;
-    c->R().ev_valid = false;
-    c->timing_slot = c->rs;
-    if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
+    const bool bracket = c->timing && c->inflight == 0;   // the slot's events belong to a submission in flight otherwise
+    if (bracket) {
+        c->R().ev_valid = false;
+        c->timing_slot = c->rs;
+        HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
+    }
     launch_geom_verify(d_gp, npairs, max_matches, d_i0, d_i1, rule, d_co, d_Fh, d_Fb, d_bc, d_Fo, d_cnt, d_s0, d_s1, d_sp, c->stream);
-    if (c->timing) {
+    if (bracket) {
         HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
         c->R().ev_valid = true;
     }

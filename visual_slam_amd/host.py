@@ -138,6 +138,16 @@ class MatWriter:
         if rc < 0:
             raise B.VsmError(rc, "vsm_mat_writer_put(%s, %s)" % (image1, image2))
 
+    def put_fmatch(self, image1, image2, idx1, idx2, F):
+        """Geometry and inlier lists of a pair whose putative record was put before."""
+        idx1 = np.ascontiguousarray(idx1, np.int32)
+        idx2 = np.ascontiguousarray(idx2, np.int32)
+        F = np.ascontiguousarray(F, np.float32).reshape(9)
+        rc = B.lib().vsm_mat_writer_put_fmatch(self._w, _b(image1), _b(image2), len(idx1), B._ptr(idx1), B._ptr(idx2), B._ptr(F))
+        if rc < 0:
+            raise IOError("vsm_mat_writer_put_fmatch failed (%d)" % rc)
+        return rc
+
     def close(self):
         if self._w:
             rc = B.lib().vsm_mat_writer_close(self._w)

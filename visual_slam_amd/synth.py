@@ -82,3 +82,34 @@ def two_view(n, seed, inlier_fraction=0.6, noise=0.5, width=1600.0, height=1200.
     F = Kinv.T @ tx @ R @ Kinv
     return (xy0.astype(np.float32), xy1.astype(np.float32), idx0[order].astype(np.int32),
             idx1[order].astype(np.int32), is_true[order], F / np.linalg.norm(F))
+
+
+def multi_view(nimages, n, seed, shared=0.6, desc_noise=4, pixel_noise=0.4):
+    """`nimages` views of one random 3-D scene for end-to-end tests: per image a keypoint array
+    [n, 2] and SIFT-like descriptors [n, 128].  round(shared * n) features of every image show scene
+    points (descriptor = the point's descriptor plus noise, keypoint = its projection plus noise, in a
+    per-image random order); the rest are unrelated.  Returns (keypoints, descriptors) lists."""
+    rng = np.random.default_rng(seed)
+    npts = int(round(shared * n))
+    X = np.stack([rng.uniform(-4, 4, npts), rng.uniform(-3, 3, npts), rng.uniform(5, 12, npts)], 1)
+    base = sift_like(npts, rng)
+    f, w, h = 1200.0, 1600.0, 1200.0
+    K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1.0]])
+    kps, dess = [], []
+    for _ in range(nimages):
+        a = rng.uniform(-0.2, 0.2, 3)
+        ca, sa = np.cos(a), np.sin(a)
+        R = (np.array([[ca[2], -sa[2], 0], [sa[2], ca[2], 0], [0, 0, 1.0]]) @ np.array([[ca[1], 0, sa[1]], [0, 1.0, 0], [-sa[1], 0, ca[1]]])
+             @ np.array([[1.0, 0, 0], [0, ca[0], -sa[0]], [0, sa[0], ca[0]]]))
+        t = rng.uniform(-1.0, 1.0, 3) * np.array([1.0, 1.0, 0.3])
+        p = (K @ (R @ X.T + t[:, None])).T
+        xy = p[:, :2] / p[:, 2:3] + pixel_noise * rng.standard_normal((npts, 2))
+        kp = np.empty((n, 2), np.float32)
+        des = sift_like(n, rng)
+        slots = rng.permutation(n)[:npts]
+        kp[:] = rng.uniform(0, [w, h], (n, 2))
+        kp[slots] = xy
+        des[slots] = np.clip(base.astype(np.int32) + rng.integers(-desc_noise, desc_noise + 1, (npts, 128)), 0, 255).astype(np.uint8)
+        kps.append(kp)
+        dess.append(des)
+    return kps, dess
