@@ -466,7 +466,7 @@ def run_geom_verify(args, torch, dist, world, rank):
                                % (npairs, nmatch, hyp),
                    "parallelism": "pair list sharded x%d" % world, "inliers_per_pair": float(np.mean(nf))},
         "roofline": {"bound": "valu", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "geom_ransac_kernel",
+                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "geom_solve_kernel + geom_score_kernel + geom_emit_kernel",
                      "kernel_ms": kms,
                      "note": "f32 vector peak; kernel_ms brackets gather + RANSAC + final scoring; the eight-point "
                              "solves (f64, LDS-resident) are not counted as work"},

@@ -12,7 +12,10 @@
  *   pivoting, free unknown 1, unit norm, de-normalisation, unit Frobenius norm (double);
  *   inliers by e^2 < t^2 (a0^2 + a1^2 + b0^2 + b1^2) in float with explicit fused multiply-adds;
  *   most inliers wins, lowest h on ties;
- *   the winner projected to rank 2 (Jacobi on F^T F), inliers re-scored, listed in match order. */
+ *   the winner projected to rank 2 (Jacobi on F^T F); four refits (least-squares eight-point fit to the
+ *   matches within 3, 2, 1, 1 thresholds of the present matrix: 64 interleaved partial sums joined by a
+ *   binary tree, unpivoted LU of the normal matrix, five inverse iterations from (1, ..., 1)); the matrix
+ *   with most inliers among the five (earliest of equals), its inliers listed in match order. */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -169,6 +172,120 @@ static void rank2(const float* Fin, float* Fout)
     for (int j = 0; j < 9; ++j) Fout[j] = fn > 0.0 ? (float)(G[j] / fn) : 0.0f;
 }
 
+/* acc[t] += acc[t + d] for d = 32, 16, ..., 1 */
+static double tree64(double* acc)
+{
+    for (int d = 32; d > 0; d >>= 1)
+        for (int t = 0; t < d; ++t) acc[t] += acc[t + d];
+    return acc[0];
+}
+
+static int count_inliers(const float* pts, int n, const float* F, float t2)
+{
+    int c = 0;
+    for (int m = 0; m < n; ++m) c += inlier(F, pts + 4 * m, t2);
+    return c;
+}
+
+static int refit(const float* pts, int n, const float* Fcur, float t2, float* Fnew)
+{
+    double acc[5][64];
+    memset(acc, 0, sizeof acc);
+    for (int m = 0; m < n; ++m)
+        if (inlier(Fcur, pts + 4 * m, t2)) {
+            const int t = m & 63;
+            acc[0][t] += 1.0;
+            for (int d = 0; d < 4; ++d) acc[1 + d][t] += (double)pts[4 * m + d];
+        }
+    const double cnt = tree64(acc[0]);
+    if (!(cnt >= 8.0)) return 0;
+    double c[4];
+    for (int d = 0; d < 4; ++d) c[d] = tree64(acc[1 + d]) / cnt;
+    double a0[64], a1[64];
+    memset(a0, 0, sizeof a0);
+    memset(a1, 0, sizeof a1);
+    for (int m = 0; m < n; ++m)
+        if (inlier(Fcur, pts + 4 * m, t2)) {
+            const float* p = pts + 4 * m;
+            const double dx0 = (double)p[0] - c[0], dy0 = (double)p[1] - c[1];
+            const double dx1 = (double)p[2] - c[2], dy1 = (double)p[3] - c[3];
+            a0[m & 63] += sqrt(dx0 * dx0 + dy0 * dy0);
+            a1[m & 63] += sqrt(dx1 * dx1 + dy1 * dy1);
+        }
+    const double md0 = tree64(a0) / cnt, md1 = tree64(a1) / cnt;
+    if (!(md0 > 0.0) || !(md1 > 0.0)) return 0;
+    const double s0 = 1.4142135623730951 / md0, s1 = 1.4142135623730951 / md1;
+    double N[45][64];
+    memset(N, 0, sizeof N);
+    for (int m = 0; m < n; ++m)
+        if (inlier(Fcur, pts + 4 * m, t2)) {
+            const float* p = pts + 4 * m;
+            const double x0 = ((double)p[0] - c[0]) * s0, y0 = ((double)p[1] - c[1]) * s0;
+            const double x1 = ((double)p[2] - c[2]) * s1, y1 = ((double)p[3] - c[3]) * s1;
+            const double r[9] = {x1 * x0, x1 * y0, x1, y1 * x0, y1 * y0, y1, x0, y0, 1.0};
+            int q = 0;
+            for (int i = 0; i < 9; ++i)
+                for (int j = i; j < 9; ++j) N[q++][m & 63] += r[i] * r[j];
+        }
+    double A[9][9];
+    {
+        int q = 0;
+        for (int i = 0; i < 9; ++i)
+            for (int j = i; j < 9; ++j) {
+                const double v = tree64(N[q++]);
+                A[i][j] = v;
+                A[j][i] = v;
+            }
+    }
+    for (int k = 0; k < 9; ++k) {
+        if (!(A[k][k] > 0.0)) return 0;
+        for (int r = k + 1; r < 9; ++r) {
+            const double f = A[r][k] / A[k][k];
+            A[r][k] = f;
+            for (int cc = k + 1; cc < 9; ++cc) A[r][cc] -= f * A[k][cc];
+        }
+    }
+    double x[9];
+    for (int j = 0; j < 9; ++j) x[j] = 1.0;
+    for (int it = 0; it < 5; ++it) {
+        double y[9], z[9];
+        for (int r = 0; r < 9; ++r) {
+            double s = x[r];
+            for (int cc = 0; cc < r; ++cc) s -= A[r][cc] * y[cc];
+            y[r] = s;
+        }
+        for (int r = 8; r >= 0; --r) {
+            double s = y[r];
+            for (int cc = r + 1; cc < 9; ++cc) s -= A[r][cc] * z[cc];
+            z[r] = s / A[r][r];
+        }
+        double nn = 0.0;
+        for (int j = 0; j < 9; ++j) nn += z[j] * z[j];
+        nn = sqrt(nn);
+        if (!(nn > 0.0) || !(nn < 1e300)) return 0;
+        for (int j = 0; j < 9; ++j) x[j] = z[j] / nn;
+    }
+    double M[9], G[9];
+    for (int i = 0; i < 3; ++i) {
+        M[3 * i + 0] = x[3 * i + 0] * s0;
+        M[3 * i + 1] = x[3 * i + 1] * s0;
+        M[3 * i + 2] = x[3 * i + 2] - (M[3 * i + 0] * c[0] + M[3 * i + 1] * c[1]);
+    }
+    for (int j = 0; j < 3; ++j) {
+        G[j] = s1 * M[j];
+        G[3 + j] = s1 * M[3 + j];
+        G[6 + j] = M[6 + j] - (G[j] * c[2] + G[3 + j] * c[3]);
+    }
+    double fn = 0.0;
+    for (int j = 0; j < 9; ++j) fn += G[j] * G[j];
+    fn = sqrt(fn);
+    if (!(fn > 0.0) || !(fn < 1e300)) return 0;
+    float Fl[9];
+    for (int j = 0; j < 9; ++j) Fl[j] = (float)(G[j] / fn);
+    rank2(Fl, Fnew);
+    return 1;
+}
+
 /* One pair.  xy0 / xy1: keypoints (n0 / n1 rows of x, y); idx0 / idx1: n putative matches.
  * pair_pos: the pair's position in the call that is being checked (part of the sampling key).
  * Out: F[9] (zeros if the pair reports nothing), in0 / in1 (capacity n).  Returns NF. */
@@ -219,8 +336,20 @@ int oracle_geom_pair(const float* xy0, int n0, const float* xy1, int n1, const i
         if (counts[h] > best) { best = counts[h]; bh = h; }
     int nf = 0;
     if (bh >= 0) {
-        float Ff[9];
-        rank2(Fs + 9 * bh, Ff);
+        float Ff[9], Fc[9], Fn[9];
+        rank2(Fs + 9 * bh, Fc);
+        int nin = count_inliers(pts, n, Fc, t2);
+        memcpy(Ff, Fc, sizeof Ff);
+        static const float widen[4] = {9.0f, 4.0f, 1.0f, 1.0f};   /* threshold^2 of the points a refit uses */
+        for (int it = 0; it < 4; ++it) {
+            if (!refit(pts, n, Fc, t2 * widen[it], Fn)) break;
+            const int cn = count_inliers(pts, n, Fn, t2);
+            if (cn > nin) {
+                nin = cn;
+                memcpy(Ff, Fn, sizeof Ff);
+            }
+            memcpy(Fc, Fn, sizeof Fc);
+        }
         for (int m = 0; m < n; ++m)
             if (inlier(Ff, pts + 4 * m, t2)) {
                 in0[nf] = idx0[m];

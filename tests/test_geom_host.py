@@ -28,7 +28,7 @@ def test_oracle_recovers_planted_geometry():
     F, in0, in1 = orc.geom_pair(xy0, xy1, i0, i1, max_sampson=2.0, hypotheses=512, seed=9)
     got = set(zip(in0.tolist(), in1.tolist()))
     want = set(zip(i0[true].tolist(), i1[true].tolist()))
-    assert len(got & want) >= 0.9 * len(want)          # nearly all true correspondences are inliers
+    assert len(got & want) >= 0.97 * len(want)         # nearly all true correspondences are inliers
     assert len(got - want) <= 0.1 * len(want)          # few wrong pairings lie on an epipolar line by chance
     F = F.astype(np.float64)
     assert abs(np.linalg.norm(F) - 1.0) < 1e-5

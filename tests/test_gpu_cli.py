@@ -118,5 +118,5 @@ def test_cli_verifies_matches_on_the_device(tmp_path):
         g0, g1 = host.get_pmatch(str(tmp_path / str(ia)), str(tmp_path / str(ib)), n)   # putative lists intact
         np.testing.assert_array_equal(g0, p0)
         kept += len(o0)
-        assert len(p0) > 150 and len(o0) > 0.3 * len(p0)
+        assert len(p0) > 150 and len(o0) > 0.9 * len(p0)      # nearly every match shows a common scene point
     assert "geometric verification: %d pairs" % len(put) in res.stderr and kept > 1000

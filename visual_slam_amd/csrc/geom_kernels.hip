@@ -15,8 +15,16 @@
 //                        in the order written in sampson_inlier)
 //   winner             : most inliers, lowest sample index among equals
 //   finish             : rank 2 enforced on the winner (f64 Jacobi eigenvectors of F^T F, the direction
-//                        of the smallest eigenvalue projected out), unit Frobenius norm, rounded to
-//                        f32, inliers re-scored with that matrix and listed in match order
+//                        of the smallest eigenvalue projected out), unit Frobenius norm, rounded to f32
+//   refit (four times) : least-squares eight-point fit to ALL matches within 3, 2, 1 and 1 thresholds of
+//                        the present matrix (a wide net first: the best sample of a noisy pair often
+//                        fits half of the true matches only): Hartley normalisation over them, the
+//                        9 x 9 normal matrix, its smallest
+//                        eigenvector by five inverse iterations from (1, ..., 1) on an unpivoted LU,
+//                        de-normalised, rank 2; sums over the inliers run over 64 interleaved partial
+//                        sums (match m in partial sum m mod 64) joined by a fixed binary tree
+//   result             : of the winner and the four refits the matrix with most inliers (the earliest
+//                        of equals), its inliers listed in match order
 //
 // Every operation is an IEEE add, multiply, fused multiply-add (only where written as one), divide,
 // square root or compare in a fixed order: results do not depend on the grid, and the file is compiled
@@ -24,7 +32,8 @@
 //
 // Kernels: gather (match coordinates), solve (one sample per thread; the 8 x 9 systems sit in LDS, which
 // limits that kernel to one wave per SIMD, so it does nothing else), score (one sample per thread, all
-// matches of the pair, workgroup-wide choice of the winner), emit (rank 2, final inlier list).
+// matches of the pair, workgroup-wide choice of the winner), emit (one wave per pair: rank 2, refits,
+// final inlier list).
 #include <hip/hip_runtime.h>
 
 #include "vsm_internal.h"
@@ -34,7 +43,7 @@ namespace vsm {
 namespace {
 
 constexpr int kGeomThreads = 128;     // hypothesis kernel: threads (samples in flight) per image pair
-constexpr int kGeomEmitThreads = 256;
+constexpr int kGeomRefits = 4;
 
 __host__ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
 {
@@ -325,56 +334,203 @@ __device__ void enforce_rank2(const float* __restrict__ Fin, float (&Fout)[9])
     for (int j = 0; j < 9; ++j) Fout[j] = fn > 0.0 ? (float)(G[j] / fn) : 0.0f;
 }
 
-// one workgroup per pair: final matrix, inliers in match order
-__global__ __launch_bounds__(kGeomEmitThreads)
+// sum over the 64 lanes in a fixed order: lane t takes lane t + d for d = 32, 16, ..., 1; the total
+// (in lane 0) goes to every lane
+__device__ __forceinline__ double wave_tree_sum(double v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    return __shfl(v, 0);
+}
+
+__device__ __forceinline__ int wave_count_inliers(const float4* __restrict__ pts, int n, const float (&F)[9], float t2, int lane)
+{
+    int c = 0;
+    for (int m = lane; m < n; m += 64) c += sampson_inlier(F, pts[m], t2) ? 1 : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    return c;
+}
+
+// Least-squares eight-point fit to the inliers of Fcur, by the whole wave (every lane ends with the same
+// values).  False when fewer than eight inliers or a degenerate system.
+__device__ bool refit_on_inliers(const float4* __restrict__ pts, int n, const float (&Fcur)[9], float t2, int lane,
+                                 float (&Fnew)[9])
+{
+    double cnt = 0, sx0 = 0, sy0 = 0, sx1 = 0, sy1 = 0;
+    for (int m = lane; m < n; m += 64) {
+        const float4 p = pts[m];
+        if (sampson_inlier(Fcur, p, t2)) {
+            cnt += 1.0;
+            sx0 += (double)p.x; sy0 += (double)p.y; sx1 += (double)p.z; sy1 += (double)p.w;
+        }
+    }
+    cnt = wave_tree_sum(cnt);
+    if (!(cnt >= 8.0)) return false;
+    const double cx0 = wave_tree_sum(sx0) / cnt, cy0 = wave_tree_sum(sy0) / cnt;
+    const double cx1 = wave_tree_sum(sx1) / cnt, cy1 = wave_tree_sum(sy1) / cnt;
+    double md0 = 0, md1 = 0;
+    for (int m = lane; m < n; m += 64) {
+        const float4 p = pts[m];
+        if (sampson_inlier(Fcur, p, t2)) {
+            const double dx0 = (double)p.x - cx0, dy0 = (double)p.y - cy0;
+            const double dx1 = (double)p.z - cx1, dy1 = (double)p.w - cy1;
+            md0 += sqrt(dx0 * dx0 + dy0 * dy0);
+            md1 += sqrt(dx1 * dx1 + dy1 * dy1);
+        }
+    }
+    md0 = wave_tree_sum(md0) / cnt;
+    md1 = wave_tree_sum(md1) / cnt;
+    if (!(md0 > 0.0) || !(md1 > 0.0)) return false;
+    const double s0 = 1.4142135623730951 / md0, s1 = 1.4142135623730951 / md1;
+    // upper triangle of the normal matrix, row by row
+    double N[45];
+#pragma unroll
+    for (int q = 0; q < 45; ++q) N[q] = 0.0;
+    for (int m = lane; m < n; m += 64) {
+        const float4 p = pts[m];
+        if (sampson_inlier(Fcur, p, t2)) {
+            const double x0 = ((double)p.x - cx0) * s0, y0 = ((double)p.y - cy0) * s0;
+            const double x1 = ((double)p.z - cx1) * s1, y1 = ((double)p.w - cy1) * s1;
+            const double r[9] = {x1 * x0, x1 * y0, x1, y1 * x0, y1 * y0, y1, x0, y0, 1.0};
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+#pragma unroll
+                for (int j = i; j < 9; ++j) N[q++] += r[i] * r[j];
+        }
+    }
+    double A[9][9];
+    {
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int j = i; j < 9; ++j) {
+                const double v = wave_tree_sum(N[q++]);
+                A[i][j] = v;
+                A[j][i] = v;
+            }
+    }
+    // LU without pivoting (the matrix is symmetric positive definite unless the points are degenerate)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (!(A[k][k] > 0.0)) return false;
+#pragma unroll
+        for (int r = k + 1; r < 9; ++r) {
+            const double f = A[r][k] / A[k][k];
+            A[r][k] = f;
+#pragma unroll
+            for (int c = k + 1; c < 9; ++c) A[r][c] -= f * A[k][c];
+        }
+    }
+    double x[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) x[j] = 1.0;
+    for (int it = 0; it < 5; ++it) {
+        double y[9], z[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double sacc = x[r];
+#pragma unroll
+            for (int c = 0; c < r; ++c) sacc -= A[r][c] * y[c];
+            y[r] = sacc;
+        }
+#pragma unroll
+        for (int r = 8; r >= 0; --r) {
+            double sacc = y[r];
+#pragma unroll
+            for (int c = r + 1; c < 9; ++c) sacc -= A[r][c] * z[c];
+            z[r] = sacc / A[r][r];
+        }
+        double nn = 0.0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) nn += z[j] * z[j];
+        nn = sqrt(nn);
+        if (!(nn > 0.0) || !(nn < 1e300)) return false;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) x[j] = z[j] / nn;
+    }
+    // F = T1^T Fn T0, unit Frobenius norm, f32, rank 2
+    double M[9], G[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        M[3 * i + 0] = x[3 * i + 0] * s0;
+        M[3 * i + 1] = x[3 * i + 1] * s0;
+        M[3 * i + 2] = x[3 * i + 2] - (M[3 * i + 0] * cx0 + M[3 * i + 1] * cy0);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        G[j] = s1 * M[j];
+        G[3 + j] = s1 * M[3 + j];
+        G[6 + j] = M[6 + j] - (G[j] * cx1 + G[3 + j] * cy1);
+    }
+    double fn = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) fn += G[j] * G[j];
+    fn = sqrt(fn);
+    if (!(fn > 0.0) || !(fn < 1e300)) return false;
+    float Fl[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) Fl[j] = (float)(G[j] / fn);
+    enforce_rank2(Fl, Fnew);
+    return true;
+}
+
+// one wave per pair: final matrix, inliers in match order
+__global__ __launch_bounds__(64)
 void geom_emit_kernel(const GeomPair* __restrict__ pairs, const float4* __restrict__ coords,
                       const int32_t* __restrict__ idx0, const int32_t* __restrict__ idx1, GeomRule rule,
                       const float* __restrict__ Fbest, const int32_t* __restrict__ best_count,
                       float* __restrict__ Fout, int32_t* __restrict__ counts,
                       int32_t* __restrict__ slot_i0, int32_t* __restrict__ slot_i1)
 {
-    __shared__ float s_F[9];
-    __shared__ int wsum[kGeomEmitThreads / 64];
-    __shared__ int base_s;
     const GeomPair gp = pairs[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x;
     const bool have = best_count[blockIdx.x] >= 0;
-    if (tid == 0) {
-        base_s = 0;
-        float F[9];
-        if (have) enforce_rank2(Fbest + (size_t)blockIdx.x * 9, F);
-        for (int j = 0; j < 9; ++j) s_F[j] = have ? F[j] : 0.0f;
-    }
-    __syncthreads();
-    float F[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) F[j] = s_F[j];
     const float t2 = rule.max_sampson * rule.max_sampson;
     const float4* __restrict__ pts = coords + gp.off;
-    for (int m0 = 0; have && m0 < gp.n; m0 += kGeomEmitThreads) {
-        const int m = m0 + tid;
-        const bool ok = m < gp.n && sampson_inlier(F, pts[m], t2);
-        const unsigned long long bal = __ballot(ok);
-        if (lane == 0) wsum[wave] = __popcll(bal);
-        __syncthreads();
-        int woff = 0, tot = 0;
-        for (int w = 0; w < kGeomEmitThreads / 64; ++w) {
-            if (w < wave) woff += wsum[w];
-            tot += wsum[w];
+    float F[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) F[j] = 0.0f;
+    int nin = 0;
+    if (have) {
+        float Fc[9];
+        enforce_rank2(Fbest + (size_t)blockIdx.x * 9, Fc);
+        nin = wave_count_inliers(pts, gp.n, Fc, t2, lane);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) F[j] = Fc[j];
+        for (int it = 0; it < kGeomRefits; ++it) {
+            float Fn[9];
+            const float widen = it == 0 ? 9.0f : it == 1 ? 4.0f : 1.0f;   // threshold^2 of the points this refit uses
+            if (!refit_on_inliers(pts, gp.n, Fc, t2 * widen, lane, Fn)) break;
+            const int cn = wave_count_inliers(pts, gp.n, Fn, t2, lane);
+            if (cn > nin) {
+                nin = cn;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) F[j] = Fn[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 9; ++j) Fc[j] = Fn[j];
         }
-        const int base = base_s;
-        __syncthreads();
-        if (tid == 0) base_s = base + tot;
-        if (ok) {
-            const size_t o = gp.off + base + woff + __popcll(bal & ((1ull << lane) - 1ull));
-            slot_i0[o] = idx0[gp.off + m];
-            slot_i1[o] = idx1[gp.off + m];
-        }
-        __syncthreads();
     }
-    if (tid == 0) {
-        const bool keep = have && base_s >= rule.min_inliers && base_s > 0;
-        counts[blockIdx.x] = keep ? base_s : 0;
+    const bool keep = have && nin >= rule.min_inliers && nin > 0;
+    if (keep) {
+        int base = 0;
+        for (int m0 = 0; m0 < gp.n; m0 += 64) {
+            const int m = m0 + lane;
+            const bool ok = m < gp.n && sampson_inlier(F, pts[m], t2);
+            const unsigned long long bal = __ballot(ok);
+            if (ok) {
+                const size_t o = gp.off + base + __popcll(bal & ((1ull << lane) - 1ull));
+                slot_i0[o] = idx0[gp.off + m];
+                slot_i1[o] = idx1[gp.off + m];
+            }
+            base += __popcll(bal);
+        }
+    }
+    if (lane == 0) {
+        counts[blockIdx.x] = keep ? nin : 0;
         for (int j = 0; j < 9; ++j) Fout[(size_t)blockIdx.x * 9 + j] = keep ? F[j] : 0.0f;
     }
 }
@@ -411,7 +567,7 @@ void launch_geom_verify(const GeomPair* pairs, int npairs, int max_matches, cons
                        dim3(kGeomThreads), geom_lds_bytes(), s, pairs, coords, rule, Fh);
     hipLaunchKernelGGL(geom_score_kernel, dim3(npairs), dim3(kGeomScoreThreads), 0, s,
                        pairs, coords, rule, Fh, Fbest, best_count);
-    hipLaunchKernelGGL(geom_emit_kernel, dim3(npairs), dim3(kGeomEmitThreads), 0, s,
+    hipLaunchKernelGGL(geom_emit_kernel, dim3(npairs), dim3(64), 0, s,
                        pairs, coords, idx0, idx1, rule, Fbest, best_count, Fout, counts, slot_i0, slot_i1);
     hipLaunchKernelGGL(geom_pack_pairs_kernel, dim3((npairs + 255) / 256), dim3(256), 0, s, pairs, npairs, pack_pairs);
 }
