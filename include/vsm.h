@@ -261,7 +261,7 @@ int vsm_mat_write_fmatch(const char* image1, const char* image2, int nf, const i
                          const int32_t* idx2, const float* F);
 /* MatchFile::GetIMatch / GetIMatchR (MatchFile.cpp:961-1084): F[9], *nf and up to cap inlier pairs;
  * returns NM of the record (0 when absent or rejected by the reference's checks). */
-/* The same through a vsm_matwriter (directories cached; see vsm_mat_writer_open). */
+/* The same through the cached writer that vsm_mat_writer_open returns. */
 int vsm_mat_writer_put_fmatch(vsm_matwriter* w, const char* image1, const char* image2, int nf,
                               const int32_t* idx1, const int32_t* idx2, const float* F);
 int vsm_mat_get_imatch(const char* image, const char* other, int fc_other, float* F, int* nf,
