@@ -163,13 +163,15 @@ int vsm_nearest_embed(vsm_ctx* ctx, const float* x, int batch, int dim, int npts
  * gets it from cv2.findEssentialMat(..., RANSAC) (models/utils.py:288-312).  The reference holds no
  * estimator of its own; this one is RANSAC over the normalised eight-point solve with Sampson-distance
  * inliers, deterministic for a given seed (samples come from a counter-based generator keyed by seed,
- * pair position in the call and sample number).  x1^T F x0 = 0 for a keypoint x0 of the pair's first
+ * the pair's key and the sample number).  x1^T F x0 = 0 for a keypoint x0 of the pair's first
  * image and its match x1 in the second; F has unit Frobenius norm and rank 2. */
 typedef struct vsm_geom_params {
     float max_sampson;   /* inlier threshold on the Sampson distance, in pixels (> 0) */
     int hypotheses;      /* samples per pair; 0 = 256 */
     unsigned seed;
     int min_inliers;     /* a pair with fewer inliers reports none (NF = 0, F = 0) */
+    long long first_pair; /* sampling key of the call's first pair; pair k of the call uses first_pair + k, so
+                           * a pair list cut into calls (or shards) in any way gives the same results */
 } vsm_geom_params;
 /* Keypoint locations of one image, n x (x, y) floats (the first two columns of a .sift location
  * record, FeaturePoints.cpp:388-446).  Returns a set id (released with vsm_release_set). */

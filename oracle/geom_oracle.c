@@ -287,10 +287,10 @@ static int refit(const float* pts, int n, const float* Fcur, float t2, float* Fn
 }
 
 /* One pair.  xy0 / xy1: keypoints (n0 / n1 rows of x, y); idx0 / idx1: n putative matches.
- * pair_pos: the pair's position in the call that is being checked (part of the sampling key).
+ * pair_key: the pair's sampling key (key of the call's first pair + position in the call).
  * Out: F[9] (zeros if the pair reports nothing), in0 / in1 (capacity n).  Returns NF. */
 int oracle_geom_pair(const float* xy0, int n0, const float* xy1, int n1, const int32_t* idx0, const int32_t* idx1, int n,
-                     float max_sampson, int hypotheses, unsigned seed, unsigned pair_pos, int min_inliers,
+                     float max_sampson, int hypotheses, unsigned seed, unsigned long long pair_key, int min_inliers,
                      float* F, int32_t* in0, int32_t* in1)
 {
     for (int j = 0; j < 9; ++j) F[j] = 0.0f;
@@ -307,7 +307,7 @@ int oracle_geom_pair(const float* xy0, int n0, const float* xy1, int n1, const i
         }
     }
     const float t2 = max_sampson * max_sampson;
-    const uint64_t base = splitmix64(((uint64_t)seed << 32) ^ (uint64_t)pair_pos);
+    const uint64_t base = splitmix64(((uint64_t)seed << 32) ^ (uint64_t)pair_key);
     int* counts = (int*)malloc((size_t)hypotheses * sizeof(int));
     float* Fs = (float*)malloc((size_t)hypotheses * 9 * sizeof(float));
 #pragma omp parallel for schedule(dynamic, 4)

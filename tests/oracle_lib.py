@@ -204,7 +204,7 @@ def geom_pair(xy0, xy1, idx0, idx1, max_sampson=2.0, hypotheses=256, seed=0, pai
     fn = lib().oracle_geom_pair
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int,
-                   C.c_uint, C.c_uint, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+                   C.c_uint, C.c_ulonglong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     nf = fn(_p(xy0), len(xy0), _p(xy1), len(xy1), _p(idx0), _p(idx1), n, float(max_sampson), int(hypotheses),
             int(seed) & 0xFFFFFFFF, int(pair_pos), int(min_inliers), _p(F), _p(in0), _p(in1))
     return F.reshape(3, 3), in0[:nf], in1[:nf]

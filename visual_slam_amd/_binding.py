@@ -112,7 +112,8 @@ SIGNATURES = {
 
 class GeomParams(C.Structure):
     """vsm_geom_params"""
-    _fields_ = [("max_sampson", C.c_float), ("hypotheses", C.c_int), ("seed", C.c_uint), ("min_inliers", C.c_int)]
+    _fields_ = [("max_sampson", C.c_float), ("hypotheses", C.c_int), ("seed", C.c_uint), ("min_inliers", C.c_int),
+                ("first_pair", C.c_longlong)]
 
 _lib = None
 
@@ -333,14 +334,14 @@ class Matcher:
         return sid
 
     def verify_matches(self, xy_pairs, offsets=None, idx0=None, idx1=None, max_sampson=2.0, hypotheses=256, seed=0,
-                       min_inliers=0, cap=None):
+                       min_inliers=0, cap=None, first_pair=0):
         """Fundamental matrix and inlier matches per pair.  With offsets/idx0/idx1 None the putative
         matches are the lists of the last collected submission, read on the device (cap: their total,
         as match_pairs_device returned it; without it the call may run twice to size the buffers).
         Returns (F [npairs, 3, 3], nf [npairs], in_offsets, in_idx0, in_idx1)."""
         xy_pairs = np.ascontiguousarray(xy_pairs, dtype=np.int32).reshape(-1, 2)
         npairs = xy_pairs.shape[0]
-        g = GeomParams(float(max_sampson), int(hypotheses), int(seed) & 0xFFFFFFFF, int(min_inliers))
+        g = GeomParams(float(max_sampson), int(hypotheses), int(seed) & 0xFFFFFFFF, int(min_inliers), int(first_pair))
         if offsets is not None:
             offsets = np.ascontiguousarray(offsets, np.int64)
             idx0 = np.ascontiguousarray(idx0, np.int32)

@@ -6,7 +6,8 @@
 // algorithm below is this library's, stated operation by operation so that the CPU checker can follow
 // it bit for bit:
 //
-//   sample h of pair p : eight distinct matches drawn from a counter-based generator (splitmix64)
+//   sample h of pair p : eight distinct matches drawn from a counter-based generator (splitmix64 of
+//                        seed, the pair's key = key of the call's first pair + position, h, draw)
 //   solve              : Hartley normalisation of the eight points (per image), the 8 x 9 system of
 //                        x1^T F x0 = 0, Gaussian elimination with complete pivoting, free variable 1,
 //                        back substitution, unit norm, de-normalisation, unit Frobenius norm (f64)
@@ -204,7 +205,7 @@ void geom_solve_kernel(const GeomPair* __restrict__ pairs, const float4* __restr
     float F[9];
     bool ok = n >= 8;
     if (ok) {
-        const unsigned long long base = splitmix64(((unsigned long long)rule.seed << 32) ^ (unsigned long long)(unsigned)blockIdx.y);
+        const unsigned long long base = splitmix64(((unsigned long long)rule.seed << 32) ^ (rule.first_pair + (unsigned long long)blockIdx.y));
         int pick[8];
         int got = 0;
         for (int ctr = 0; ctr < 64 && got < 8; ++ctr) {

@@ -206,9 +206,11 @@ int main(int argc, char** argv)
     }
 
     // this process's slice of the pair list
+    long long first_of_shard = 0;
     if (o.nshards > 1) {
         const long long per = (npairs + o.nshards - 1) / o.nshards;
         const long long lo = std::min<long long>(npairs, per * o.shard), hi = std::min<long long>(npairs, lo + per);
+        first_of_shard = lo;
         pairs.erase(pairs.begin(), pairs.begin() + 2 * lo);
         pairs.resize((size_t)(hi - lo) * 2 + 2);
         npairs = hi - lo;
@@ -374,6 +376,7 @@ int main(int argc, char** argv)
             b.in_off.resize((size_t)take + 1);
             b.in0.resize((size_t)got + 1);
             b.in1.resize((size_t)got + 1);
+            gprm.first_pair = first_of_shard + lo;   // global position in the pair list: sharding and batching do not change the samples
             const long long gin = vsm_verify_matches(ctx, xy_ids.data(), take, nullptr, nullptr, nullptr, &gprm, b.F.data(),
                                                      b.nf.data(), b.in_off.data(), b.in0.data(), b.in1.data(), got);
             if (gin < 0) {

@@ -1427,6 +1427,7 @@ extern "C" long long vsm_verify_matches(vsm_ctx* c, const int32_t* xy_pairs, int
     rule.hypotheses = nhyp;
     rule.seed = g->seed;
     rule.min_inliers = g->min_inliers;
+    rule.first_pair = (unsigned long long)g->first_pair;
     const bool bracket = c->timing && c->inflight == 0;   // the slot's events belong to a submission in flight otherwise
     if (bracket) {
         c->R().ev_valid = false;

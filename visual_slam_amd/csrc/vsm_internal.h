@@ -179,6 +179,7 @@ struct GeomRule {
     int hypotheses;      // samples per pair
     unsigned seed;
     int min_inliers;     // pairs with fewer inliers report none
+    unsigned long long first_pair;   // sampling key of the call's first pair
 };
 size_t geom_lds_bytes();
 void launch_geom_verify(const GeomPair* pairs, int npairs, int max_matches, const int32_t* idx0, const int32_t* idx1,
