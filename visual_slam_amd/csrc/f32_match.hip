@@ -73,6 +73,24 @@ void launch_f32_accept(const SiftPair* pairs, const F32PairRef* refs, int npairs
     hipLaunchKernelGGL(f32_accept_kernel, dim3(npairs), dim3(1024), 0, s, pairs, refs, rule, j1, k1, k2, out);
 }
 
+__global__ void gather_words_kernel(WordSegments seg, uint32_t* __restrict__ dst)
+{
+    int base = 0;
+    for (int k = 0; k < seg.n; ++k) {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < seg.count[k]; i += gridDim.x * blockDim.x)
+            dst[base + i] = seg.src[k][i];
+        base += seg.count[k];
+    }
+}
+
+void launch_gather_words(const WordSegments& seg, uint32_t* dst, hipStream_t s)
+{
+    int total = 0;
+    for (int k = 0; k < seg.n; ++k) total += seg.count[k];
+    if (total <= 0) return;
+    hipLaunchKernelGGL(gather_words_kernel, dim3(std::min(64, (total + 255) / 256)), dim3(256), 0, s, seg, dst);
+}
+
 // ---- merge of per-slice 2-NN lists (database cut into contiguous row ranges) ---------------
 // packed: [nslices][4][nq] 32-bit words = best key, runner-up key (float bits), best row, runner-up
 // row (slice-local, -1 = none).  Order: key, then global row (lower first), as on the host.

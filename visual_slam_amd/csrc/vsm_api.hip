@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -92,7 +93,8 @@ struct vsm_ctx {
     DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_flag, d_probs, d_refs, d_geom;
     // float sets: 0 = bf16 coarse pass + exact re-rank (exact kernel when a survivor list overflows), 1 = exact kernel only
     int f32_mode = 0, last_f32_path = -1;
-    HostBuf h_small, h_probs, h_refs;
+    int* flag_dev = nullptr;   // survivor-overflow flag of the last coarse submission (inside d_probs)
+    HostBuf h_small, h_probs, h_refs, h_gather;
     // Two sets of per-submission staging and result buffers, so that vsm_match_pairs can queue
     // submission k + 1 while the match lists of submission k travel to the host on copy_stream.
     struct ResultSlot {
@@ -414,6 +416,7 @@ extern "C" void vsm_destroy(vsm_ctx* c)
     c->h_small.release();
     c->h_probs.release();
     c->h_refs.release();
+    c->h_gather.release();
     for (auto& r : c->slots)
         for (hipEvent_t ev : {r.ev0, r.ev1, r.ev2, r.ev3})
             if (ev) (void)hipEventDestroy(ev);
@@ -629,7 +632,10 @@ CoarseProblem make_problem(const DescSet* A, const DescSet* B, int metric)
 // Plans `probs` (non-empty searches only), uploads them and queues the coarse + re-rank kernels.
 // Results land in d_knnj / d_rrj (best and runner-up row) and d_knn1 / d_knn2 (their keys) at each
 // problem's out_off; the overflow flag is cleared first and must be read back by the caller.
-int queue_coarse(vsm_ctx* c, std::vector<CoarseProblem>& probs, int dim, size_t min_rows)
+// One host-to-device copy carries the cleared flag, the problems and `extra_bytes` more of the caller's
+// (filled through *extra_host before this returns is too late: pass a filler).
+int queue_coarse(vsm_ctx* c, std::vector<CoarseProblem>& probs, int dim, size_t min_rows, size_t extra_bytes = 0,
+                 const std::function<void(char*)>& fill_extra = nullptr, char** extra_dev = nullptr)
 {
     const CoarseTotals t = plan_coarse(probs.data(), (int)probs.size(), 1024);
     const size_t rows = std::max<size_t>(std::max<size_t>((size_t)t.out_rows, min_rows), 1);
@@ -638,18 +644,23 @@ int queue_coarse(vsm_ctx* c, std::vector<CoarseProblem>& probs, int dim, size_t 
     HIPCHK(c, c->d_knn1.ensure(rows * 4));
     HIPCHK(c, c->d_knn2.ensure(rows * 4));
     HIPCHK(c, c->d_coarse.ensure(coarse_scratch_bytes(t)));
-    HIPCHK(c, c->d_flag.ensure(256));
     HIPCHK(c, c->h_small.ensure(64));
-    HIPCHK(c, hipMemsetAsync(c->d_flag.p, 0, sizeof(int), c->stream));
-    if (probs.empty()) return VSM_OK;
-    const size_t bytes = sizeof(CoarseProblem) * probs.size();
+    // block layout: [flag, 256 bytes][problems][extra]
+    const size_t pbytes = (sizeof(CoarseProblem) * probs.size() + 255) & ~(size_t)255;
+    const size_t bytes = 256 + pbytes + extra_bytes;
     HIPCHK(c, c->h_probs.ensure(bytes));
     HIPCHK(c, c->d_probs.ensure(bytes));
-    memcpy(c->h_probs.p, probs.data(), bytes);
-    HIPCHK(c, hipMemcpyAsync(c->d_probs.p, c->h_probs.p, bytes, hipMemcpyHostToDevice, c->stream));
-    launch_bf16_batch(c->d_probs.as<CoarseProblem>(), (int)probs.size(), dim, t, c->d_knnj.as<int32_t>(),
-                      c->d_rrj.as<int32_t>(), c->d_knn1.as<float>(), c->d_knn2.as<float>(), c->d_coarse.p,
-                      c->d_flag.as<int>(), c->stream);
+    char* h = c->h_probs.as<char>();
+    memset(h, 0, 256);
+    if (!probs.empty()) memcpy(h + 256, probs.data(), sizeof(CoarseProblem) * probs.size());
+    if (extra_bytes && fill_extra) fill_extra(h + 256 + pbytes);
+    HIPCHK(c, hipMemcpyAsync(c->d_probs.p, h, bytes, hipMemcpyHostToDevice, c->stream));
+    c->flag_dev = c->d_probs.as<int>();
+    if (extra_dev) *extra_dev = c->d_probs.as<char>() + 256 + pbytes;
+    if (probs.empty()) return VSM_OK;
+    launch_bf16_batch(reinterpret_cast<const CoarseProblem*>(c->d_probs.as<char>() + 256), (int)probs.size(), dim, t,
+                      c->d_knnj.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_knn1.as<float>(), c->d_knn2.as<float>(),
+                      c->d_coarse.p, c->flag_dev, c->stream);
     return VSM_OK;
 }
 
@@ -657,7 +668,7 @@ int queue_coarse(vsm_ctx* c, std::vector<CoarseProblem>& probs, int dim, size_t 
 int coarse_overflowed(vsm_ctx* c, bool* overflow)
 {
     int* flag = c->h_small.as<int>() + 8;
-    HIPCHK(c, hipMemcpyAsync(flag, c->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(flag, c->flag_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     *overflow = *flag != 0;
@@ -826,20 +837,28 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     c->R().ev_valid = false;
     c->timing_slot = c->rs;
     if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
-    int rc = queue_coarse(c, pl.probs, pl.dim, 0);
+    // the pair records and their references to the searches travel in the same copy as the problems
+    const size_t pair_bytes = (sizeof(SiftPair) * (size_t)npairs + 255) & ~(size_t)255;
+    const size_t ref_bytes = sizeof(F32PairRef) * (size_t)npairs;
+    char* extra_dev = nullptr;
+    int rc = queue_coarse(c, pl.probs, pl.dim, 0, pair_bytes + ref_bytes, [&](char* h) {
+        // plan_coarse has run: problem offsets are final
+        for (F32PairRef& rf : pl.refs) {
+            if (rf.fwd_off >= 0) rf.fwd_off = pl.probs[rf.fwd_off].out_off;
+            if (rf.bwd_off >= 0) rf.bwd_off = pl.probs[rf.bwd_off].out_off;
+        }
+        if (npairs) {
+            memcpy(h, pl.pairs.data(), sizeof(SiftPair) * npairs);
+            memcpy(h + pair_bytes, pl.refs.data(), ref_bytes);
+        }
+    }, &extra_dev);
     if (rc) return rc;
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
         c->R().ev_valid = true;
     }
-    for (F32PairRef& rf : pl.refs) {
-        if (rf.fwd_off >= 0) rf.fwd_off = pl.probs[rf.fwd_off].out_off;
-        if (rf.bwd_off >= 0) rf.bwd_off = pl.probs[rf.bwd_off].out_off;
-    }
-    HIPCHK(c, c->R().h_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
-    HIPCHK(c, c->d_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
-    HIPCHK(c, c->h_refs.ensure(sizeof(F32PairRef) * std::max(npairs, 1)));
-    HIPCHK(c, c->d_refs.ensure(sizeof(F32PairRef) * std::max(npairs, 1)));
+    const SiftPair* d_pairs = reinterpret_cast<const SiftPair*>(extra_dev);
+    const F32PairRef* d_refs = reinterpret_cast<const F32PairRef*>(extra_dev + pair_bytes);
     const size_t n0 = std::max<size_t>(pl.out0, 1), n1 = std::max<size_t>(pl.out1, 1);
     HIPCHK(c, c->d_slot0.ensure(n0 * 4));
     HIPCHK(c, c->d_slot1.ensure(n0 * 4));
@@ -858,10 +877,6 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
         HIPCHK(c, hipMemsetAsync(c->R().d_offsets.p, 0, sizeof(int64_t), c->stream));
         return VSM_OK;
     }
-    memcpy(c->R().h_pairs.p, pl.pairs.data(), sizeof(SiftPair) * npairs);
-    memcpy(c->h_refs.p, pl.refs.data(), sizeof(F32PairRef) * npairs);
-    HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->R().h_pairs.p, sizeof(SiftPair) * npairs, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_refs.p, c->h_refs.p, sizeof(F32PairRef) * npairs, hipMemcpyHostToDevice, c->stream));
     SiftOutputs out{};
     out.slot_i0 = c->d_slot0.as<int32_t>();
     out.slot_i1 = c->d_slot1.as<int32_t>();
@@ -869,10 +884,10 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     out.counts = c->d_counts.as<int32_t>();
     out.dense0 = o.want_dense ? c->d_dense0.as<int32_t>() : nullptr;
     out.dense1 = o.want_dense ? c->d_dense1.as<int32_t>() : nullptr;
-    launch_f32_accept(c->d_pairs.as<SiftPair>(), c->d_refs.as<F32PairRef>(), npairs, rule, c->d_knnj.as<int32_t>(),
+    launch_f32_accept(d_pairs, d_refs, npairs, rule, c->d_knnj.as<int32_t>(),
                       c->d_knn1.as<float>(), c->d_knn2.as<float>(), out, c->stream);
     if (o.want_pack)
-        launch_pack(c->d_pairs.as<SiftPair>(), npairs, out.counts, c->R().d_offsets.as<int64_t>(), out.slot_i0, out.slot_i1,
+        launch_pack(d_pairs, npairs, out.counts, c->R().d_offsets.as<int64_t>(), out.slot_i0, out.slot_i1,
                     c->R().d_tight0.as<int32_t>(), c->R().d_tight1.as<int32_t>(), c->stream);
     HIPCHK(c, hipGetLastError());
     return VSM_OK;
@@ -919,26 +934,44 @@ int f32_single_pair_fast(vsm_ctx* c, const DescSet* A, const DescSet* B, int set
     o.want_dist = dist != nullptr;
     o.want_dense = dense0 != nullptr;
     if ((rc = run_f32_batch(c, pl, make_f32_rule(p, metric), o)) != VSM_OK) return rc;
-    int* flag = c->h_small.as<int>() + 8;
-    int32_t* cnt = c->h_small.as<int32_t>();
-    HIPCHK(c, hipMemcpyAsync(flag, c->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    const size_t take = (size_t)std::min(std::max(cap, 0), A->n);   // a pair has at most nA matches
-    if (take) {
-        if (idx0) HIPCHK(c, hipMemcpyAsync(idx0, c->d_slot0.p, take * 4, hipMemcpyDeviceToHost, c->stream));
-        if (idx1) HIPCHK(c, hipMemcpyAsync(idx1, c->d_slot1.p, take * 4, hipMemcpyDeviceToHost, c->stream));
-        if (dist) HIPCHK(c, hipMemcpyAsync(dist, c->d_slotd.p, take * 4, hipMemcpyDeviceToHost, c->stream));
-    }
-    if (dense0 && A->n) HIPCHK(c, hipMemcpyAsync(dense0, c->d_dense0.p, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
-    if (dense1 && B->n) HIPCHK(c, hipMemcpyAsync(dense1, c->d_dense1.p, sizeof(int32_t) * B->n, hipMemcpyDeviceToHost, c->stream));
+    // everything the caller gets goes into one device block, one copy to pinned memory, one wait
+    const int take = std::min(std::max(cap, 0), A->n);   // a pair has at most nA matches
+    WordSegments seg{};
+    void* dst_host[8];
+    auto add = [&](const void* src, int words, void* host) {
+        if (words <= 0) return;
+        seg.src[seg.n] = static_cast<const uint32_t*>(src);
+        seg.count[seg.n] = words;
+        dst_host[seg.n] = host;
+        ++seg.n;
+    };
+    int flag_host = 0, cnt_host = 0;
+    add(c->flag_dev, 1, &flag_host);
+    add(c->d_counts.p, 1, &cnt_host);
+    if (idx0) add(c->d_slot0.p, take, idx0);
+    if (idx1) add(c->d_slot1.p, take, idx1);
+    if (dist) add(c->d_slotd.p, take, dist);
+    if (dense0) add(c->d_dense0.p, A->n, dense0);
+    if (dense1) add(c->d_dense1.p, B->n, dense1);
+    size_t words = 0;
+    for (int k = 0; k < seg.n; ++k) words += (size_t)seg.count[k];
+    HIPCHK(c, c->d_stage.ensure(words * 4));
+    HIPCHK(c, c->h_gather.ensure(words * 4));
+    launch_gather_words(seg, c->d_stage.as<uint32_t>(), c->stream);
+    HIPCHK(c, hipMemcpyAsync(c->h_gather.p, c->d_stage.p, words * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
-    if (*flag != 0) {
+    const uint32_t* got = c->h_gather.as<uint32_t>();
+    for (int k = 0; k < seg.n; ++k) {
+        memcpy(dst_host[k], got, (size_t)seg.count[k] * 4);
+        got += seg.count[k];
+    }
+    if (flag_host != 0) {
         c->R().ev_valid = false;
         return kNotDone;
     }
     c->last_f32_path = 0;
-    return *cnt;
+    return cnt_host;
 }
 
 // Per-pair path on the f32 kernel; leaves offsets and tight lists on the device like a submission.

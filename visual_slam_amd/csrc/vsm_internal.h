@@ -165,6 +165,15 @@ void launch_sift_verify(const SiftPair* pairs, int npairs, SiftItem* vitems, int
 void launch_sift_confirm(const SiftPair* pairs, int npairs, SiftCandidates cand, int mutual,
                          SiftOutputs out, hipStream_t s);
 // counts[npairs] -> offsets[npairs+1] (exclusive scan), then slots -> tight arrays
+// Several device arrays of 32-bit words copied end to end into one (so that one copy brings a small
+// result to the host).
+struct WordSegments {
+    const uint32_t* src[8];
+    int count[8];
+    int n;
+};
+void launch_gather_words(const WordSegments& seg, uint32_t* dst, hipStream_t s);
+
 // ---- geometric verification of putative matches -----------------------------------------
 struct GeomPair {
     const float* xy0;   // keypoints of image 0: n0 x (x, y)
