@@ -103,3 +103,34 @@ def test_inlier_records_round_trip(tmp_path):
     # a wrong feature count is rejected as the reference does, and an unknown partner reports nothing
     assert vsm.get_imatch(a, b, 399)[0] == 0
     assert vsm.write_fmatch(a, str(tmp_path / "other"), p0[:1], p1[:1], F) == 0
+
+
+def test_cached_writer_leaves_the_same_files(tmp_path):
+    """vsm_mat_writer_put + put_fmatch over many pairs = one write_pmatch + write_fmatch call per pair."""
+    rng = np.random.default_rng(6)
+    n = 6
+    fc = [int(x) for x in rng.integers(200, 400, n)]
+    recs = []
+    for a in range(n):
+        for b in range(a + 1, n):
+            nm = int(rng.integers(0, 60))
+            p0 = np.sort(rng.permutation(fc[a])[:nm]).astype(np.int32)
+            p1 = rng.permutation(fc[b])[:nm].astype(np.int32)
+            sel = np.sort(rng.permutation(nm)[: nm // 2])
+            recs.append((a, b, p0, p1, sel, rng.standard_normal((3, 3)).astype(np.float32)))
+    d1, d2 = tmp_path / "one", tmp_path / "two"
+    d1.mkdir()
+    d2.mkdir()
+    for a, b, p0, p1, sel, F in recs:
+        vsm.write_pmatch(str(d1 / str(a)), str(d1 / str(b)), fc[a], fc[b], p0, p1)
+        vsm.write_fmatch(str(d1 / str(a)), str(d1 / str(b)), p0[sel], p1[sel], F)
+    from visual_slam_amd import host
+    with host.MatWriter() as w:
+        for a, b, p0, p1, sel, F in recs:
+            w.put(str(d2 / str(a)), str(d2 / str(b)), fc[a], fc[b], p0, p1)
+            w.put_fmatch(str(d2 / str(a)), str(d2 / str(b)), p0[sel], p1[sel], F)
+    for i in range(n):
+        assert open(str(d1 / ("%d.mat" % i)), "rb").read() == open(str(d2 / ("%d.mat" % i)), "rb").read()
+    a, b, p0, p1, sel, F = recs[3]
+    nm, Fg, r0, r1 = vsm.get_imatch(str(d2 / str(a)), str(d2 / str(b)), fc[b])
+    assert nm == len(p0) or len(p0) == 0
