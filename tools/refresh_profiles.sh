@@ -21,6 +21,8 @@ stats db_query --workload db_query
 stats superpoint_pair --workload superpoint_pair --steps 50
 stats superpoint_pairs --workload superpoint_pairs
 stats sift_large_pair --workload sift_large_pair
+stats geom_verify --workload geom_verify
+timeout -k 10 300 python3 $root/bench.py --workload geom_verify > $out/${tag}_bench_geom_verify.json.log 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   timeout -s KILL 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $root/tools/traffic_probe.py --images 1000 > /tmp/pmc_$c.log 2>&1
