@@ -738,11 +738,10 @@ static void launch_coarse_t(const CoarseProblem* d_probs, int nprobs, int blocks
                             int* overflow, hipStream_t s)
 {
     const int lds = 2 * kCoarseStepBytes;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceFlags attr_set;   // the attribute is per device
+    if (first_launch_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_coarse_kernel<DIMP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL(bf16_coarse_kernel<DIMP>, dim3(blocks), dim3(kCoarseWaves * 64), lds, s,
                        d_probs, nprobs, part, lists, overflow);

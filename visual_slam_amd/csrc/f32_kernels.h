@@ -2,6 +2,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include "device_flags.h"
 #include <stdint.h>
 
 namespace vsm {

@@ -293,11 +293,10 @@ static void launch_knn_t(const F32Problem& pr, int nstrips, int nsplits, int tps
                          hipStream_t s)
 {
     const int lds = 2 * 32 * DIMP * 4 + 512;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceFlags attr_set;   // the attribute is per device
+    if (first_launch_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f32_knn_kernel<DIMP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL(f32_knn_kernel<DIMP>, dim3(nstrips * nsplits), dim3(512), lds, s,
                        pr, nstrips, tps, qpart, colpart);

@@ -558,11 +558,10 @@ void launch_geom_verify(const GeomPair* pairs, int npairs, int max_matches, cons
     if (npairs <= 0) return;
     const int gx = std::max(1, std::min(64, (max_matches + 255) / 256));
     hipLaunchKernelGGL(geom_gather_kernel, dim3(gx, npairs), dim3(256), 0, s, pairs, npairs, idx0, idx1, coords);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceFlags attr_set;   // the attribute is per device
+    if (first_launch_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(geom_solve_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom_lds_bytes());
-        attr_set = true;
     }
     hipLaunchKernelGGL(geom_solve_kernel, dim3((rule.hypotheses + kGeomThreads - 1) / kGeomThreads, npairs),
                        dim3(kGeomThreads), geom_lds_bytes(), s, pairs, coords, rule, Fh);

@@ -285,11 +285,10 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
 void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
                        int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceFlags attr_set;   // the attribute is per device
+    if (first_launch_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sift_query_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsStream);
-        attr_set = true;
     }
     hipLaunchKernelGGL(sift_query_kernel, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
                        pairs, items, rr_d1, rr_j1, rr_d2, -512);
@@ -458,11 +457,10 @@ void launch_sift_verify(const SiftPair* pairs, int npairs, SiftItem* vitems, int
 {
     if (npairs <= 0 || max_vitems <= 0) return;
     hipLaunchKernelGGL(sift_verify_plan_kernel, dim3(1), dim3(1024), 0, s, cand.count, npairs, vitems, nvitems);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceFlags attr_set;   // the attribute is per device
+    if (first_launch_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sift_verify_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsStream);
-        attr_set = true;
     }
     hipLaunchKernelGGL(sift_verify_kernel, dim3(kVerifyGrid), dim3(kVerifyWaves * 64), kLdsStream, s,
                        pairs, vitems, nvitems, cand, -512);
