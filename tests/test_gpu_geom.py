@@ -113,3 +113,15 @@ def test_rejects_descriptor_sets_and_bad_arguments(matcher):
         matcher.match_pair(x, x)
     matcher.release(s)
     matcher.release(x)
+
+
+def test_estimate_fundamental_helper(matcher):
+    xy0, xy1, i0, i1, true, Ftrue = synth.two_view(500, seed=95, inlier_fraction=0.8, noise=0.4)
+    got = vsm.estimate_fundamental(matcher, xy0[i0], xy1[i1], 1.5, samples=300, seed=2)
+    assert got is not None
+    F, mask = got
+    assert mask.sum() >= 0.97 * true.sum() and (mask & ~true).sum() <= 0.05 * true.sum()
+    oF, o0, _ = orc.geom_pair(xy0[i0], xy1[i1], np.arange(500), np.arange(500), max_sampson=1.5, hypotheses=300, seed=2)
+    np.testing.assert_array_equal(F, oF)
+    np.testing.assert_array_equal(np.nonzero(mask)[0], o0)
+    assert vsm.estimate_fundamental(matcher, xy0[:7], xy1[:7], 1.5) is None

@@ -250,3 +250,29 @@ def get_imatch(image, other, fc_other):
 def get_imatch_r(image, other, fc_other):
     """MatchFile::GetIMatchR (MatchFile.cpp:1025-1084)."""
     return _get_imatch(B.lib().vsm_mat_get_imatch_r, image, other, fc_other)
+
+
+def estimate_fundamental(matcher, kpts0, kpts1, thresh, samples=256, seed=0):
+    """Geometry of one pair from its matched keypoints, in the calling style of estimate_pose
+    (models/utils.py:288-312: matched keypoint arrays in, model and inlier mask out; None when there
+    are too few matches).  Returns (F [3, 3], mask [n] bool) with x1^T F x0 = 0; `thresh` is the Sampson
+    distance in pixels.  (The reference goes on to an essential matrix and a pose with the camera
+    intrinsics through OpenCV; that part is not rebuilt here.)"""
+    kpts0 = np.ascontiguousarray(kpts0, np.float32)
+    kpts1 = np.ascontiguousarray(kpts1, np.float32)
+    n = len(kpts0)
+    if n < 8:
+        return None
+    s0, s1 = matcher.upload_xy(kpts0), matcher.upload_xy(kpts1)
+    try:
+        idx = np.arange(n, dtype=np.int32)
+        F, nf, in_off, i0, _ = matcher.verify_matches([(s0, s1)], np.array([0, n], np.int64), idx, idx,
+                                                      max_sampson=thresh, hypotheses=samples, seed=seed)
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)
+    if nf[0] == 0:
+        return None
+    mask = np.zeros(n, bool)
+    mask[i0] = True
+    return F[0], mask
