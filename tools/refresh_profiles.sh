@@ -30,3 +30,26 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "pmc $c done"
 done
 python3 $root/tools/pmc_summary.py $out/${tag}_probe1000_pmc_FETCH_SIZE.csv $out/${tag}_probe1000_pmc_WRITE_SIZE.csv $out/${tag}_traffic_sift_exhaustive.json
+# matrix-core utilisation of the SIFT kernels: busy cycles of the matrix pipes against elapsed cycles x SIMDs
+rm -rf /tmp/pmc_mfma
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INSTS_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_mfma -- python3 $root/tools/traffic_probe.py --images 300 > /tmp/pmc_mfma.log 2>&1
+cp "$(find /tmp/pmc_mfma -name '*counter_collection.csv' | head -1)" $out/${tag}_probe300_pmc_mfma.csv
+python3 - $out/${tag}_probe300_pmc_mfma.csv <<'PY' | tee $out/${tag}_mfma_utilisation.txt
+import collections, csv, sys
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+n = collections.defaultdict(set)
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"].split("(")[0]
+    acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    n[k].add(r["Dispatch_Id"])
+for k, v in acc.items():
+    if "sift_query" not in k and "sift_verify_kernel" not in k:
+        continue
+    d = len(n[k])
+    # GRBM_GUI_ACTIVE comes summed over the 8 XCDs; the busy cycles are summed over all 1024 SIMDs
+    busy, act = v["SQ_VALU_MFMA_BUSY_CYCLES"] / d, v["GRBM_GUI_ACTIVE"] / d / 8.0
+    print("%s: %d launches; per launch: matrix-pipe busy cycles %.4g, elapsed cycles %.4g, busy / (elapsed x 1024 SIMDs) = %.3f; "
+          "MFMA mops %.4g, VALU instructions %.4g, co-execution cycles %.4g"
+          % (k, d, busy, act, busy / (act * 1024.0), v["SQ_INSTS_VALU_MFMA_MOPS_I8"] / d, v["SQ_INSTS_VALU"] / d,
+             v["SQ_VALU_MFMA_COEXEC_CYCLES"] / d))
+PY
