@@ -122,7 +122,7 @@ struct CoarsePart {   // per (split, query, lane half): coarse top-2 values and 
 };
 
 // Workgroup = 4 waves; wave w keeps the bf16 operands of kCoarseRB x 32 queries in registers (the
-// accumulator's lane axis), the database streams through LDS in 32 KiB steps (LDS-DMA, double
+// accumulator's lane axis), the database streams through LDS in 16 KiB steps (LDS-DMA, double
 // buffered) and every tile read from LDS feeds kCoarseRB MFMA chains.
 // Survivor lists are stored 64 at a time, entry-major: the e-th entries of 64 consecutive lists (the
 // 32 queries x 2 lane halves one wave of the coarse kernel serves) are adjacent, so the part of the
@@ -135,7 +135,7 @@ __device__ __forceinline__ size_t list_slot(size_t sublist, int e)
 constexpr int kCoarseRB = 2;
 constexpr int kCoarseWaves = 4;
 constexpr int kCoarseStripRows = kCoarseWaves * kCoarseRB * 32;  // queries per workgroup
-constexpr int kCoarseStepBytes = 32768;
+constexpr int kCoarseStepBytes = 16384;
 static_assert(kF32RowPad % kCoarseStripRows == 0, "query strips must tile the padded row count");
 
 // The accumulators start from a per-row constant instead of zero: -|b|^2 / 2 for the L2 ranking (the
@@ -163,7 +163,7 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
     constexpr int S = DIMP / 16;             // k-steps (MFMAs) per tile
     constexpr int RB = kCoarseRB;
     constexpr int TILE_BYTES = 32 * DIMP * 2;
-    constexpr int STEP_TILES = kCoarseStepBytes / TILE_BYTES;   // 2, 4 or 8
+    constexpr int STEP_TILES = kCoarseStepBytes / TILE_BYTES;   // 1, 2 or 4
     constexpr int STEP_ROWS = STEP_TILES * 32;
     // database steps, double buffered; the two buffers and the two constant arrays are addressed with
     // compile-time indices so that reads of one are known not to touch the DMA target of the other
