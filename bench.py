@@ -40,6 +40,19 @@ def measured_traffic(kernel):
         return None
 
 
+def measured_mfma_busy(kernel):
+    """Fraction of the elapsed SIMD cycles in which the matrix pipes were busy, from the committed counter
+    pass (profiles/r01_mfma_utilisation.txt, written by tools/refresh_profiles.sh); None when absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_mfma_utilisation.txt")
+    try:
+        for line in open(path):
+            if line.startswith(kernel + ":") and "SIMDs) = " in line:
+                return float(line.split("SIMDs) = ")[1].split(";")[0])
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 def f32_roofline(m, flops, kms):
     """Roofline object of a float-descriptor search: priced against the matrix-core peak of the
     path that actually ran (bf16 coarse pass + exact re-rank, or the f32-input kernel)."""
@@ -246,6 +259,10 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
                      "frac": achieved / INT8_DENSE_PEAK_TOPS,
                      "traffic": measured_traffic("vsm::sift_query_kernel")
                      if (nimg, nfeat, launch_pairs) == (1000, 8192, 2048) else None,
+                     "mfma_busy_frac": measured_mfma_busy("vsm::sift_query_kernel")
+                     if (nimg, nfeat, launch_pairs) == (1000, 8192, 2048) else None,
+                     "mfma_busy_note": "matrix-pipe busy cycles / (elapsed cycles x SIMDs) from a separate counter pass "
+                                       "(profiles/r01_mfma_utilisation.txt); the chip clocks at about 1.85 GHz under this load",
                      "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes "
                                      "(profiles/r01_probe1000_pmc_*.csv; FETCH_SIZE doubled as gfx950 needs); "
                                      "algorithmic operand bytes per launch: %d" % (launch_pairs * 2 * nfeat * 128),
