@@ -90,11 +90,11 @@ struct vsm_ctx {
     // workspace (grow-only)
     DevBuf d_pairs, d_items, d_rr1, d_rrj, d_rr2, d_colpart, d_cand;
     DevBuf d_slot0, d_slot1, d_slotd, d_counts;
-    DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_flag, d_probs, d_refs, d_geom;
+    DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_probs, d_geom;
     // float sets: 0 = bf16 coarse pass + exact re-rank (exact kernel when a survivor list overflows), 1 = exact kernel only
     int f32_mode = 0, last_f32_path = -1;
     int* flag_dev = nullptr;   // survivor-overflow flag of the last coarse submission (inside d_probs)
-    HostBuf h_small, h_probs, h_refs, h_gather;
+    HostBuf h_small, h_probs, h_gather;
     // Two sets of per-submission staging and result buffers, so that vsm_match_pairs can queue
     // submission k + 1 while the match lists of submission k travel to the host on copy_stream.
     struct ResultSlot {
@@ -400,8 +400,8 @@ extern "C" void vsm_destroy(vsm_ctx* c)
     }
     DevBuf* bufs[] = {&c->d_pairs, &c->d_items, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart, &c->d_cand,
                       &c->d_slot0, &c->d_slot1, &c->d_slotd, &c->d_counts, &c->d_dense0, &c->d_dense1,
-                      &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage, &c->d_coarse, &c->d_flag,
-                      &c->d_probs, &c->d_refs, &c->d_geom};
+                      &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage, &c->d_coarse,
+                      &c->d_probs, &c->d_geom};
     for (DevBuf* b : bufs) b->release();
     for (auto& r : c->slots) {
         r.d_offsets.release();
@@ -415,7 +415,6 @@ extern "C" void vsm_destroy(vsm_ctx* c)
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->h_small.release();
     c->h_probs.release();
-    c->h_refs.release();
     c->h_gather.release();
     for (auto& r : c->slots)
         for (hipEvent_t ev : {r.ev0, r.ev1, r.ev2, r.ev3})
