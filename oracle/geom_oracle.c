@@ -132,7 +132,7 @@ static void rank2(const float* Fin, float* Fout)
             V[3 * i + j] = i == j ? 1.0 : 0.0;
         }
     static const int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
-    for (int sweep = 0; sweep < 12; ++sweep)
+    for (int sweep = 0; sweep < 6; ++sweep)
         for (int pq = 0; pq < 3; ++pq) {
             const int p = P[pq], q = Q[pq];
             const double apq = S[3 * p + q];

@@ -293,7 +293,7 @@ __device__ void enforce_rank2(const float* __restrict__ Fin, float (&Fout)[9])
             S[3 * i + j] = (F[i] * F[j] + F[3 + i] * F[3 + j]) + F[6 + i] * F[6 + j];   // (F^T F)[i][j]
             V[3 * i + j] = i == j ? 1.0 : 0.0;
         }
-    for (int sweep = 0; sweep < 12; ++sweep) {
+    for (int sweep = 0; sweep < 6; ++sweep) {
         for (int pq = 0; pq < 3; ++pq) {
             const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
             const double apq = S[3 * p + q];
