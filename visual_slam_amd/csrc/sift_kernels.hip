@@ -170,8 +170,8 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
     const int lane5 = lane & 31;
     const int half = lane >> 5;
 
-    const int c0 = it.chunk * kChunkCols;
-    const int ncols = min(kChunkCols, pw.nB_pad - c0);
+    const int c0 = it.chunk * pw.chunk_cols;
+    const int ncols = min(pw.chunk_cols, pw.nB_pad - c0);
     const int nsteps = ncols / kStepRows;  // sets are padded to whole steps
 
     // persistent operand: this wave's query rows

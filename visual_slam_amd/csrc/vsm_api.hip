@@ -186,6 +186,14 @@ int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
     pl.pairs.resize(npairs);
     pl.items.clear();
     pl.max_vitems = 0;
+    // A submission of few pairs (one pair per call is the common case of a per-pair loop) is cut into
+    // narrower chunks of the train set, so that its query pass still has a few hundred workgroups.
+    long long strips_total = 0;
+    for (int p = 0; p < npairs; ++p) {
+        const DescSet* A = get_set(c, pairs[2 * p]);
+        if (A && A->kind == SET_U8) strips_total += A->n_pad / kStripRows;
+    }
+    const long long kWantItems = 256;
     for (int p = 0; p < npairs; ++p) {
         const DescSet* A = get_set(c, pairs[2 * p]);
         const DescSet* B = get_set(c, pairs[2 * p + 1]);
@@ -199,7 +207,15 @@ int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
         sp.nA = A->n; sp.nB = B->n; sp.nA_pad = A->n_pad; sp.nB_pad = B->n_pad;
         const bool empty = A->n == 0 || B->n == 0;
         sp.nstrips = empty ? 0 : A->n_pad / kStripRows;
-        sp.nchunks = empty ? 0 : (B->n_pad + kChunkCols - 1) / kChunkCols;
+        int chunk_cols = kChunkCols;
+        if (!empty && strips_total * ((B->n_pad + kChunkCols - 1) / kChunkCols) < kWantItems) {
+            const long long want_chunks = (kWantItems + strips_total - 1) / strips_total;
+            const long long cols = ((long long)B->n_pad + want_chunks - 1) / want_chunks;
+            chunk_cols = (int)std::min<long long>(kChunkCols, std::max<long long>(2 * kStepRows, (cols + kStepRows - 1) / kStepRows * kStepRows));
+        }
+        sp.chunk_cols = chunk_cols;
+        sp.pad0 = 0;
+        sp.nchunks = empty ? 0 : (B->n_pad + chunk_cols - 1) / chunk_cols;
         sp.row_off = (int64_t)pl.rows;
         sp.out0_off = (int64_t)pl.out0;
         sp.out1_off = (int64_t)pl.out1;

@@ -27,7 +27,7 @@ constexpr int kTileBytes = 4096;      // 32 rows * 128 bytes
 constexpr int kStripRows = 512;       // query rows per workgroup of the query pass (4 waves * 128)
 constexpr int kVerifyBlock = 256;     // candidates per workgroup of the verify pass (4 waves * 64)
 constexpr int kStepRows = 256;        // streamed rows per main-loop step
-constexpr int kChunkCols = 8192;      // streamed rows per work item of the query-side pass
+constexpr int kChunkCols = 8192;      // streamed rows per work item of the query-side pass, at most
 constexpr int32_t kNormPad = 0x7FFFFF00;
 constexpr int32_t kDistPad = 0x7FFFFF;  // (kNormPad >> 8): "no such neighbour"
 
@@ -39,6 +39,7 @@ struct SiftPair {
     int32_t nA, nB;          // real row counts
     int32_t nA_pad, nB_pad;  // padded to kRowPad
     int32_t nstrips, nchunks;
+    int32_t chunk_cols, pad0;   // train rows per work item of the query pass (a multiple of kStepRows)
     int64_t row_off;   // into the per-(chunk,row) partial arrays: nchunks * nA_pad entries
     int64_t out0_off;  // into per-query-row arrays (nA entries): candidates, outputs
     int64_t out1_off;  // into per-train-row outputs (nB entries)
