@@ -1275,18 +1275,39 @@ extern "C" int vsm_match_pair(vsm_ctx* c, int set0, int set1, const vsm_params* 
     o.want_dist = dist != nullptr;
     o.want_pack = false;
     if ((rc = run_u8(c, pl, make_rule(p), o)) != VSM_OK) return rc;
-    HIPCHK(c, c->h_small.ensure(64));
-    int32_t* cnt = c->h_small.as<int32_t>();
-    HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    // count and lists in one block, one copy, one wait (a pair has at most nA matches)
+    const DescSet* A = get_set(c, set0);
+    const int take = std::min(std::max(cap, 0), A->n);
+    WordSegments seg{};
+    void* dst_host[8];
+    auto add = [&](const void* src, int words, void* host) {
+        if (words <= 0) return;
+        seg.src[seg.n] = static_cast<const uint32_t*>(src);
+        seg.count[seg.n] = words;
+        dst_host[seg.n] = host;
+        ++seg.n;
+    };
+    int nm = 0;
+    add(c->d_counts.p, 1, &nm);
+    if (idx0) add(c->d_slot0.p, take, idx0);
+    if (idx1) add(c->d_slot1.p, take, idx1);
+    if (dist) add(c->d_slotd.p, take, dist);
+    size_t words = 0;
+    for (int k = 0; k < seg.n; ++k) words += (size_t)seg.count[k];
+    HIPCHK(c, c->d_stage.ensure(words * 4));
+    HIPCHK(c, c->h_gather.ensure(words * 4));
+    launch_gather_words(seg, c->d_stage.as<uint32_t>(), c->stream);
+    HIPCHK(c, hipMemcpyAsync(c->h_gather.p, c->d_stage.p, words * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const int nm = *cnt;
-    if (nm > cap) return fail(c, VSM_ECAP, "%d matches do not fit a buffer of %d", nm, cap);
-    if (nm > 0) {
-        if (idx0) HIPCHK(c, hipMemcpyAsync(idx0, c->d_slot0.p, sizeof(int32_t) * nm, hipMemcpyDeviceToHost, c->stream));
-        if (idx1) HIPCHK(c, hipMemcpyAsync(idx1, c->d_slot1.p, sizeof(int32_t) * nm, hipMemcpyDeviceToHost, c->stream));
-        if (dist) HIPCHK(c, hipMemcpyAsync(dist, c->d_slotd.p, sizeof(int32_t) * nm, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    const uint32_t* got = c->h_gather.as<uint32_t>();
+    for (int k = 0; k < seg.n; ++k) {
+        // the first segment is the count; list segments hold `take` slots of which nm are filled
+        const size_t fill = k == 0 ? 1 : (size_t)std::min(nm, take);
+        memcpy(dst_host[k], got, fill * 4);
+        got += seg.count[k];
     }
+    if (nm > cap) return fail(c, VSM_ECAP, "%d matches do not fit a buffer of %d", nm, cap);
     return nm;
 }
 
