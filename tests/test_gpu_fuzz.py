@@ -139,3 +139,37 @@ def test_geometry_random(matcher, seed):
         for a, b in ids:
             matcher.release(a)
             matcher.release(b)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_large_sets_random(matcher, seed):
+    """Sizes that span several 8192-row chunks and 512-row strips, one call per pair and as a list."""
+    rng = np.random.default_rng(9950 + seed)
+    n0, n1 = int(rng.integers(7000, 21000)), int(rng.integers(7000, 21000))
+    a, b = synth.sift_pair(n0, n1, seed=50 + seed, planted=0.3)
+    s0, s1 = matcher.upload_u8(a), matcher.upload_u8(b)
+    try:
+        for mutual in (True, False):
+            o0, o1, od = orc.match_u8(a, b, orc.params((4, 5), mutual))
+            g0, g1, gd = matcher.match_pair(s0, s1, ratio=0.8, mutual=mutual, return_dist=True)
+            np.testing.assert_array_equal(g0, o0)
+            np.testing.assert_array_equal(g1, o1)
+            np.testing.assert_array_equal(gd, od)
+            off, i0, i1 = matcher.match_pairs([[s0, s1], [s1, s0], [s0, s1]], ratio=0.8, mutual=mutual)
+            np.testing.assert_array_equal(i0[off[0]:off[1]], o0)
+            np.testing.assert_array_equal(i1[off[2]:off[3]], o1)
+            r0, r1, _ = orc.match_u8(b, a, orc.params((4, 5), mutual))
+            np.testing.assert_array_equal(i0[off[1]:off[2]], r0)
+            np.testing.assert_array_equal(i1[off[1]:off[2]], r1)
+        fa, fb = synth.superpoint_pair(n0 // 3, n1 // 2, 256, seed=60 + seed)
+        q0, q1 = matcher.upload_f32(fa), matcher.upload_f32(fb)
+        gi1, gi2, gk1, gk2 = matcher.knn2(q0, q1, vsm.METRIC_L2, want_idx2=True)
+        oi, ok1, ok2 = orc.knn2_f32(fa, fb, orc.METRIC_L2)
+        np.testing.assert_array_equal(gi1, oi)
+        np.testing.assert_array_equal(gk1, ok1)
+        np.testing.assert_array_equal(gk2, ok2)
+        matcher.release(q0)
+        matcher.release(q1)
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)
