@@ -230,6 +230,17 @@ int vsm_image_pairs(int nimages, int consecutive, const int32_t* discrete, int n
                     int32_t* pairs, int cap);
 /* All i<j pairs (exhaustive matching).  Returns the pair count. */
 long long vsm_image_pairs_exhaustive(int nimages, int32_t* pairs, long long cap);
+/* Pair list by content, for collections that are not a sequence (generate_imagePairs, main.py:157-169,
+ * goes by position only; the reference has no counterpart of this).  sets[nimg] are resident
+ * descriptor sets, vocab_set a resident set of visual words of the same kind and dimension.  Every
+ * descriptor row takes its nearest word (squared L2, lowest row among equals); a word held by df of
+ * the nimg images weighs 1 + floor(log2(nimg / df)) (integer quotient); the score of two images is
+ * the sum over words of weight * min(count in one, count in the other); every image chooses its
+ * topk partners by (score descending, position ascending), scores of 0 excluded.  pairs receives the
+ * union of the choices as positions in sets[], i < j, in ascending (i, j) order; scores (may be NULL)
+ * the [nimg][nimg] score matrix.  All integer arithmetic.  Returns the pair count. */
+long long vsm_shortlist_pairs(vsm_ctx* ctx, const int32_t* sets, int nimg, int vocab_set, int topk,
+                              int32_t* pairs, long long cap, int32_t* scores);
 /* MatchFile::WritePMatch(image1, image2, fc1, fc2, NM, matches) (MatchFile.cpp:751-832):
  * image paths without extension; writes <image1>.mat and <image2>.mat.
  * reservation = MatchFile::SetRecordReservation (MatchFile.h:244); pass 0 for the

@@ -87,6 +87,10 @@ void orc_merge_top2_f32(const float* k1, const float* k2, const int32_t* i1, con
                         int nslices, int nq, int metric,
                         float* ok1, float* ok2, int32_t* oi1, int32_t* oi2);
 
+/* ---- image-pair shortlist (shortlist_oracle.c) ------------------------------- */
+long long orc_shortlist(const int32_t* words, const int64_t* offsets, int nimg, int nwords, int topk,
+                        int32_t* pairs, long long cap, int32_t* scores);
+
 /* ---- formats ---------------------------------------------------------------- */
 /* FeaturePoints.cpp:228-280 / :388-446.  Returns bytes written or <0. */
 long orc_sift_write(const char* path, const float* loc, int nloc_dim,

@@ -208,3 +208,20 @@ def geom_pair(xy0, xy1, idx0, idx1, max_sampson=2.0, hypotheses=256, seed=0, pai
     nf = fn(_p(xy0), len(xy0), _p(xy1), len(xy1), _p(idx0), _p(idx1), n, float(max_sampson), int(hypotheses),
             int(seed) & 0xFFFFFFFF, int(pair_pos), int(min_inliers), _p(F), _p(in0), _p(in1))
     return F.reshape(3, 3), in0[:nf], in1[:nf]
+
+
+def shortlist(words_per_image, nwords, topk):
+    """Pair shortlist from per-image word assignments; returns (pairs [n, 2], scores [nimg, nimg])."""
+    nimg = len(words_per_image)
+    off = np.zeros(nimg + 1, np.int64)
+    for i, w in enumerate(words_per_image):
+        off[i + 1] = off[i] + len(w)
+    words = np.ascontiguousarray(np.concatenate([np.asarray(w, np.int32) for w in words_per_image] + [np.zeros(0, np.int32)]))
+    cap = max(nimg * (nimg - 1) // 2, 1)
+    pairs = np.empty((cap, 2), np.int32)
+    scores = np.zeros((max(nimg, 1), max(nimg, 1)), np.int32)
+    fn = lib().orc_shortlist
+    fn.restype = C.c_longlong
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
+    n = fn(_p(words), _p(off), nimg, int(nwords), int(topk), _p(pairs), cap, _p(scores))
+    return pairs[:n], scores[:nimg, :nimg]

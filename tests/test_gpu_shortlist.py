@@ -1,0 +1,85 @@
+"""GPU parity: the image-pair shortlist through the C ABI against the CPU oracle.  Bar: pair list and
+score matrix identical (integer arithmetic on word assignments that are themselves bit-exact nearest
+neighbours).  The reference has no content-based pair selection: parity unpinned."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+import visual_slam_amd as vsm
+from visual_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _words(images, vocab):
+    if images[0].dtype == np.uint8:
+        return [orc.knn2_u8(img, vocab)[0] if len(img) else np.zeros(0, np.int32) for img in images]
+    return [orc.knn2_f32(img, vocab, orc.METRIC_L2)[0] if len(img) else np.zeros(0, np.int32) for img in images]
+
+
+def _check(matcher, images, vocab, topk):
+    up = matcher.upload_u8 if vocab.dtype == np.uint8 else matcher.upload_f32
+    ids = [up(img) for img in images]
+    vid = up(vocab)
+    try:
+        pairs, scores = matcher.shortlist_pairs(ids, vid, topk, want_scores=True)
+    finally:
+        for s in ids + [vid]:
+            matcher.release(s)
+    epairs, escores = orc.shortlist(_words(images, vocab), len(vocab), topk)
+    np.testing.assert_array_equal(scores, escores)
+    np.testing.assert_array_equal(pairs, epairs)
+    return pairs
+
+
+def test_groups_of_sift_images(matcher):
+    images, group = synth.image_groups(8, 5, 700, seed=11, shared=0.5)
+    vocab = synth.sample_vocabulary(images, 1000, seed=12)
+    pairs = _check(matcher, images, vocab, 4)
+    same = group[pairs[:, 0]] == group[pairs[:, 1]]
+    assert same.sum() == 8 * 10 and same.mean() > 0.9
+
+
+@pytest.mark.parametrize("nimg,n,nwords,topk", [(1, 50, 10, 3), (2, 33, 1, 1), (3, 600, 513, 2), (70, 90, 97, 5),
+                                                  (130, 40, 64, 200), (65, 257, 2048, 7)])
+def test_shapes_sift(matcher, nimg, n, nwords, topk):
+    rng = np.random.default_rng(nimg * 1000 + n)
+    images = [synth.sift_like(max(int(rng.integers(n // 2, n + 1)), 1), rng) for _ in range(nimg)]
+    # a few near-copies so that equal scores and shared words occur
+    for k in range(1, nimg, 3):
+        images[k] = images[k - 1].copy()
+    vocab = synth.sample_vocabulary(images, nwords, seed=n)
+    _check(matcher, images, vocab, topk)
+
+
+def test_empty_image_and_duplicate_words(matcher):
+    rng = np.random.default_rng(2)
+    images = [synth.sift_like(100, rng), np.zeros((0, 128), np.uint8), synth.sift_like(80, rng), synth.sift_like(100, rng)]
+    vocab = synth.sift_like(20, rng)
+    vocab[7] = vocab[3]          # equal words: the lower row takes all
+    pairs = _check(matcher, images, vocab, 2)
+    assert not (pairs == 1).any()   # the empty image scores 0 with everything
+
+
+@pytest.mark.parametrize("dim", [256, 64])
+def test_float_descriptors(matcher, dim):
+    images, group = synth.image_groups(5, 4, 400, seed=21, shared=0.5, noise=0.01, dtype="f32", dim=dim)
+    vocab = synth.sample_vocabulary(images, 1000, seed=22)
+    pairs = _check(matcher, images, vocab, 3)
+    same = group[pairs[:, 0]] == group[pairs[:, 1]]
+    assert same.sum() == 5 * 6
+
+
+def test_rejects_bad_arguments(matcher):
+    rng = np.random.default_rng(3)
+    a = matcher.upload_u8(synth.sift_like(10, rng))
+    f = matcher.upload_f32(synth.unit_f32(10, 256, rng))
+    with pytest.raises(vsm.VsmError):
+        matcher.shortlist_pairs([a, f], a, 2)        # mixed kinds
+    with pytest.raises(vsm.VsmError):
+        matcher.shortlist_pairs([a, a], 999, 2)      # no such vocabulary
+    with pytest.raises(vsm.VsmError):
+        matcher.shortlist_pairs([a, a], a, 0)        # topk < 1
+    assert len(matcher.shortlist_pairs([], a, 2)) == 0
+    # the context still works afterwards
+    assert len(matcher.shortlist_pairs([a, a], a, 1)) == 1

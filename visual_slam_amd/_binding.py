@@ -90,6 +90,8 @@ SIGNATURES = {
     "vsm_matchtxt_close": (C.c_int, [C.c_void_p]),
     "vsm_image_pairs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "vsm_image_pairs_exhaustive": (C.c_longlong, [C.c_int, C.c_void_p, C.c_longlong]),
+    "vsm_shortlist_pairs": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong,
+                                           C.c_void_p]),
     "vsm_mat_write_pmatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "vsm_mat_writer_open": (C.c_void_p, [C.c_int, C.c_int]),
     "vsm_mat_writer_put": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -322,6 +324,20 @@ class Matcher:
         self._check(self._l.vsm_nearest_embed(self._h, _ptr(x), b, d, npts, _ptr(emb), emb.shape[1],
                                               _ptr(argmin), _ptr(res)))
         return (res.reshape(x.shape) if want_result else None), argmin.reshape((b,) + tuple(x.shape[2:]))
+
+    # ---- pair list by content -----------------------------------------------------------
+    def shortlist_pairs(self, sets, vocab_set, topk, want_scores=False):
+        """Image pairs worth matching, from word histograms over the vocabulary ``vocab_set``: every
+        image's ``topk`` best partners by weighted histogram intersection.  Returns int32 [npairs, 2]
+        positions in ``sets`` (i < j, ascending), and the [n, n] score matrix if asked for."""
+        sets = np.ascontiguousarray(sets, dtype=np.int32).reshape(-1)
+        n = sets.shape[0]
+        cap = min(n * min(int(topk), n), n * (n - 1) // 2)
+        pairs = np.empty((max(cap, 1), 2), np.int32)
+        scores = np.empty((n, n), np.int32) if want_scores else None
+        got = self._check(self._l.vsm_shortlist_pairs(self._h, _ptr(sets), n, int(vocab_set), int(topk), _ptr(pairs),
+                                                      cap, _ptr(scores)))
+        return (pairs[:got], scores) if want_scores else pairs[:got]
 
     # ---- geometric verification ---------------------------------------------------------
     def upload_xy(self, xy):

@@ -1,0 +1,243 @@
+// Image-pair shortlist from a visual vocabulary: word histograms, weights, histogram-intersection
+// scores, best partners of every image, ordered pair list.  All integer arithmetic, so the result does
+// not depend on the order in which the device adds things up.
+//
+// The reference chooses pairs by position in the sequence only (generate_imagePairs, main.py:157-169);
+// this is the content-based counterpart for unordered collections.
+#include "vsm_internal.h"
+
+#include <algorithm>
+
+namespace vsm {
+
+namespace {
+
+constexpr int kScoreTile = 64;   // images per side of a score tile (256 threads, 4 x 4 scores each)
+constexpr int kScoreStep = 32;   // words per LDS step
+
+// One block column per image of the submission: words[offsets[p] .. offsets[p+1]) are the nearest
+// vocabulary rows of image first_image + p.
+__global__ __launch_bounds__(256) void bow_count_kernel(const int64_t* __restrict__ offsets,
+                                                        const int32_t* __restrict__ words, int first_image,
+                                                        int nwords, uint32_t* __restrict__ hist)
+{
+    const int p = blockIdx.y;
+    const int64_t lo = offsets[p], hi = offsets[p + 1];
+    uint32_t* h = hist + (size_t)(first_image + p) * nwords;
+    for (int64_t r = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; r < hi; r += (int64_t)gridDim.x * 256) {
+        const int w = words[r];
+        if (w >= 0 && w < nwords) atomicAdd(&h[w], 1u);
+    }
+}
+
+// weight[w] = 0 for a word no image holds, else 1 + floor(log2(nimg / df)) with the integer quotient.
+__global__ __launch_bounds__(256) void bow_weight_kernel(const uint32_t* __restrict__ hist, int nimg, int nwords,
+                                                         uint32_t* __restrict__ weight)
+{
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwords) return;
+    int df = 0;
+    for (int i = 0; i < nimg; ++i) df += hist[(size_t)i * nwords + w] != 0u;
+    weight[w] = df ? (uint32_t)(32 - __clz(nimg / df)) : 0u;
+}
+
+__global__ __launch_bounds__(256) void bow_scale_kernel(uint32_t* __restrict__ hist, const uint32_t* __restrict__ weight,
+                                                        int nwords, size_t total)
+{
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (size_t)gridDim.x * 256)
+        hist[k] *= weight[k % (size_t)nwords];
+}
+
+// scores[i][j] = sum over words of min(g[i][w], g[j][w]) for the weighted histograms g; tiles on and
+// above the diagonal are computed and written to both triangles.
+__global__ __launch_bounds__(256) void bow_score_kernel(const uint32_t* __restrict__ g, int nimg, int nwords,
+                                                        int32_t* __restrict__ scores)
+{
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;
+    __shared__ uint32_t sa[kScoreStep][kScoreTile + 1];
+    __shared__ uint32_t sb[kScoreStep][kScoreTile + 1];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int kk = tid & 31, r0 = tid >> 5;
+    uint32_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0u;
+    for (int k0 = 0; k0 < nwords; k0 += kScoreStep) {
+        const bool kin = k0 + kk < nwords;
+#pragma unroll
+        for (int r = r0; r < kScoreTile; r += 8) {
+            const int ia = bi * kScoreTile + r, ib = bj * kScoreTile + r;
+            sa[kk][r] = (kin && ia < nimg) ? g[(size_t)ia * nwords + k0 + kk] : 0u;
+            sb[kk][r] = (kin && ib < nimg) ? g[(size_t)ib * nwords + k0 + kk] : 0u;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < kScoreStep; ++k) {
+            uint32_t va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                va[u] = sa[k][ty * 4 + u];
+                vb[u] = sb[k][tx * 4 + u];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += min(va[a], vb[b]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = bi * kScoreTile + ty * 4 + a, j = bj * kScoreTile + tx * 4 + b;
+            if (i < nimg && j < nimg) {
+                scores[(size_t)i * nimg + j] = (int32_t)acc[a][b];
+                scores[(size_t)j * nimg + i] = (int32_t)acc[a][b];
+            }
+        }
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, d), hi = __shfl_xor((unsigned)(v >> 32), d);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// One workgroup per image: its topk partners by (score descending, image ascending), scores of 0
+// excluded; every choice marks the unordered pair.
+__global__ __launch_bounds__(256) void bow_topk_kernel(const int32_t* __restrict__ scores, int nimg, int topk,
+                                                       uint8_t* __restrict__ mark)
+{
+    __shared__ unsigned long long s_part[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int32_t* row = scores + (size_t)i * nimg;
+    unsigned long long prev = ~0ull;
+    for (int r = 0; r < topk; ++r) {
+        unsigned long long best = 0ull;
+        for (int j = tid; j < nimg; j += 256) {
+            const int32_t s = row[j];
+            if (j == i || s <= 0) continue;
+            const unsigned long long key = ((unsigned long long)(uint32_t)s << 32) | (0xFFFFFFFFu - (uint32_t)j);
+            if (key < prev && key > best) best = key;
+        }
+        best = wave_max_u64(best);
+        __syncthreads();   // the previous round's s_part has been read by every thread
+        if ((tid & 63) == 0) s_part[tid >> 6] = best;
+        __syncthreads();
+        best = s_part[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) best = s_part[w] > best ? s_part[w] : best;
+        if (best == 0ull) break;   // the same value in every thread
+        if (tid == 0) {
+            const int j = (int)(0xFFFFFFFFu - (uint32_t)best);
+            const int a = i < j ? i : j, b = i < j ? j : i;
+            mark[(size_t)a * nimg + b] = 1;
+        }
+        prev = best;
+    }
+}
+
+__global__ __launch_bounds__(256) void bow_rowcount_kernel(const uint8_t* __restrict__ mark, int nimg,
+                                                           int32_t* __restrict__ counts)
+{
+    __shared__ int s_part[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    int n = 0;
+    for (int j = i + 1 + tid; j < nimg; j += 256) n += mark[(size_t)i * nimg + j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d);
+    if ((tid & 63) == 0) s_part[tid >> 6] = n;
+    __syncthreads();
+    if (tid == 0) counts[i] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+// offsets[0..nimg] = exclusive sums of counts; one workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void bow_offsets_kernel(const int32_t* __restrict__ counts, int nimg,
+                                                           int64_t* __restrict__ offsets)
+{
+    __shared__ int64_t s_wave[16];
+    __shared__ int64_t s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < nimg; i0 += 1024) {
+        const int i = i0 + tid;
+        const int64_t v = i < nimg ? counts[i] : 0;
+        int64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int64_t woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) woff += s_wave[w];
+            tot += s_wave[w];
+        }
+        const int64_t base = s_base;
+        if (i < nimg) offsets[i] = base + woff + incl - v;
+        __syncthreads();
+        if (tid == 0) s_base = base + tot;
+        __syncthreads();
+    }
+    if (tid == 0) offsets[nimg] = s_base;
+}
+
+// Row i of the marks, in ascending j, into pairs[offsets[i] ..].
+__global__ __launch_bounds__(1024) void bow_emit_kernel(const uint8_t* __restrict__ mark, int nimg,
+                                                        const int64_t* __restrict__ offsets, int32_t* __restrict__ pairs)
+{
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    const int64_t out = offsets[i];
+    if (offsets[i + 1] == out) return;   // the same in every thread
+    for (int j0 = i + 1; j0 < nimg; j0 += 1024) {
+        const int j = j0 + tid;
+        const bool flag = j < nimg && mark[(size_t)i * nimg + j] != 0;
+        const int slot = block_compact_slot(flag, wsum, &base_s);
+        if (flag) {
+            pairs[2 * (out + slot)] = i;
+            pairs[2 * (out + slot) + 1] = j;
+        }
+    }
+}
+
+}  // namespace
+
+void launch_bow_count(const int64_t* offsets, const int32_t* words, int first_image, int nimages, int nwords,
+                      uint32_t* hist, hipStream_t s)
+{
+    if (nimages <= 0) return;
+    hipLaunchKernelGGL(bow_count_kernel, dim3(32, nimages), dim3(256), 0, s, offsets, words, first_image, nwords, hist);
+}
+
+void launch_bow_shortlist(uint32_t* hist, int nimg, int nwords, int topk, uint32_t* weight, int32_t* scores,
+                          uint8_t* mark, int32_t* counts, int64_t* offsets, int32_t* pairs, hipStream_t s)
+{
+    if (nimg <= 0) return;
+    const size_t total = (size_t)nimg * nwords;
+    hipLaunchKernelGGL(bow_weight_kernel, dim3((nwords + 255) / 256), dim3(256), 0, s, hist, nimg, nwords, weight);
+    const unsigned sblocks = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
+    hipLaunchKernelGGL(bow_scale_kernel, dim3(sblocks), dim3(256), 0, s, hist, weight, nwords, total);
+    const int tiles = (nimg + kScoreTile - 1) / kScoreTile;
+    hipLaunchKernelGGL(bow_score_kernel, dim3(tiles, tiles), dim3(256), 0, s, hist, nimg, nwords, scores);
+    hipLaunchKernelGGL(bow_topk_kernel, dim3(nimg), dim3(256), 0, s, scores, nimg, topk, mark);
+    hipLaunchKernelGGL(bow_rowcount_kernel, dim3(nimg), dim3(256), 0, s, mark, nimg, counts);
+    hipLaunchKernelGGL(bow_offsets_kernel, dim3(1), dim3(1024), 0, s, counts, nimg, offsets);
+    hipLaunchKernelGGL(bow_emit_kernel, dim3(nimg), dim3(1024), 0, s, mark, nimg, offsets, pairs);
+}
+
+}  // namespace vsm

@@ -90,7 +90,7 @@ struct vsm_ctx {
     // workspace (grow-only)
     DevBuf d_pairs, d_items, d_rr1, d_rrj, d_rr2, d_colpart, d_cand;
     DevBuf d_slot0, d_slot1, d_slotd, d_counts;
-    DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_probs, d_geom;
+    DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_probs, d_geom, d_short;
     // float sets: 0 = bf16 coarse pass + exact re-rank (exact kernel when a survivor list overflows), 1 = exact kernel only
     int f32_mode = 0, last_f32_path = -1;
     int* flag_dev = nullptr;   // survivor-overflow flag of the last coarse submission (inside d_probs)
@@ -417,7 +417,7 @@ extern "C" void vsm_destroy(vsm_ctx* c)
     DevBuf* bufs[] = {&c->d_pairs, &c->d_items, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart, &c->d_cand,
                       &c->d_slot0, &c->d_slot1, &c->d_slotd, &c->d_counts, &c->d_dense0, &c->d_dense1,
                       &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage, &c->d_coarse,
-                      &c->d_probs, &c->d_geom};
+                      &c->d_probs, &c->d_geom, &c->d_short};
     for (DevBuf* b : bufs) b->release();
     for (auto& r : c->slots) {
         r.d_offsets.release();
@@ -1662,4 +1662,89 @@ extern "C" int vsm_nearest_embed(vsm_ctx* c, const float* x, int batch, int dim,
     }
     vsm_release_set(c, code_set);
     return rc < 0 ? rc : VSM_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// image-pair shortlist from a visual vocabulary
+// ---------------------------------------------------------------------------------
+extern "C" long long vsm_shortlist_pairs(vsm_ctx* c, const int32_t* sets, int nimg, int vocab_set, int topk,
+                                         int32_t* pairs, long long cap, int32_t* scores)
+{
+    if (!c) return VSM_EINVAL;
+    if (nimg < 0 || (nimg > 0 && !sets) || topk < 1 || cap < 0 || (cap > 0 && !pairs)) return fail(c, VSM_EINVAL, "bad argument");
+    if (nimg > 16384) return fail(c, VSM_EINVAL, "%d images in one shortlist (limit 16384)", nimg);
+    if (c->inflight) return fail(c, VSM_EINVAL, "collect the submissions in flight first");
+    const DescSet* V = get_set(c, vocab_set);
+    if (!V || (V->kind != SET_U8 && V->kind != SET_F32) || V->n < 1)
+        return fail(c, VSM_EINVAL, "set %d is not a vocabulary (a descriptor set of at least one row)", vocab_set);
+    const int K = V->n;
+    constexpr int kMaxRows = 1 << 26;   // 15 (largest weight for 16384 images) x rows stays below 2^31
+    for (int i = 0; i < nimg; ++i) {
+        const DescSet* A = get_set(c, sets[i]);
+        if (!A || A->kind != V->kind || A->dim != V->dim)
+            return fail(c, VSM_EINVAL, "image %d (set %d) is not a descriptor set of the vocabulary's kind and dimension", i, sets[i]);
+        if (A->n > kMaxRows) return fail(c, VSM_EINVAL, "image %d has %d rows (limit %d)", i, A->n, kMaxRows);
+    }
+    if (nimg == 0) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t n2 = (size_t)nimg * nimg;
+    const size_t max_pairs = std::min<size_t>((size_t)nimg * (size_t)std::min(topk, nimg), n2 / 2 + 1);
+    const size_t b_hist = up((size_t)nimg * K * 4), b_w = up((size_t)K * 4), b_sc = up(n2 * 4), b_mark = up(n2);
+    const size_t b_cnt = up((size_t)nimg * 4), b_off = up(((size_t)nimg + 1) * 8), b_pairs = up(max_pairs * 8);
+    const size_t need = b_hist + b_w + b_sc + b_mark + b_cnt + b_off + b_pairs;
+    if (need > c->scratch_budget)
+        return fail(c, VSM_EINVAL, "shortlist of %d images over %d words needs %zu bytes of scratch (limit %zu)", nimg, K, need, c->scratch_budget);
+    HIPCHK(c, c->d_short.ensure(need));
+    char* w = c->d_short.as<char>();
+    uint32_t* d_hist = reinterpret_cast<uint32_t*>(w); w += b_hist;
+    uint32_t* d_w = reinterpret_cast<uint32_t*>(w); w += b_w;
+    int32_t* d_sc = reinterpret_cast<int32_t*>(w); w += b_sc;
+    uint8_t* d_mark = reinterpret_cast<uint8_t*>(w); w += b_mark;
+    int32_t* d_cnt = reinterpret_cast<int32_t*>(w); w += b_cnt;
+    int64_t* d_off = reinterpret_cast<int64_t*>(w); w += b_off;
+    int32_t* d_pairs = reinterpret_cast<int32_t*>(w); w += b_pairs;
+    HIPCHK(c, hipMemsetAsync(d_hist, 0, b_hist, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_mark, 0, b_mark, c->stream));
+    // nearest vocabulary row of every descriptor row: submissions of (image, vocabulary) pairs with every test off
+    vsm_params prm{};
+    prm.ratio_num = 0; prm.ratio_den = 1; prm.mutual = 0;
+    prm.max_dist_sq = -1; prm.min_score = -INFINITY; prm.max_dist_sq_f = -1.0f;
+    const int64_t rows_per_group = (int64_t)std::max<size_t>(c->scratch_budget / (4 * kScratchPerRow), 1);
+    std::vector<int32_t> pl;
+    for (int g0 = 0; g0 < nimg;) {
+        pl.clear();
+        int64_t rows = 0;
+        int g1 = g0;
+        while (g1 < nimg && g1 - g0 < 4096) {
+            const int n = get_set(c, sets[g1])->n;
+            if (g1 > g0 && rows + n > rows_per_group) break;
+            rows += n;
+            pl.push_back(sets[g1]);
+            pl.push_back(vocab_set);
+            ++g1;
+        }
+        const long long got = vsm_match_pairs_device(c, pl.data(), g1 - g0, &prm, VSM_METRIC_L2);
+        if (got < 0) return got;
+        if (got != rows) return fail(c, VSM_ENODEV, "internal: %lld word assignments for %lld rows", got, (long long)rows);
+        const vsm_ctx::ResultSlot& R = c->slots[c->last_slot];
+        launch_bow_count(R.d_offsets.as<int64_t>(), R.d_tight1.as<int32_t>(), g0, g1 - g0, K, d_hist, c->stream);
+        g0 = g1;
+    }
+    c->last_npairs = 0;   // the resident lists were an intermediate of this call
+    c->last_total = 0;
+    launch_bow_shortlist(d_hist, nimg, K, std::min(topk, nimg), d_w, d_sc, d_mark, d_cnt, d_off, d_pairs, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, c->h_small.ensure(64));
+    long long* tot = c->h_small.as<long long>();
+    HIPCHK(c, hipMemcpyAsync(tot, d_off + nimg, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (scores) HIPCHK(c, hipMemcpyAsync(scores, d_sc, n2 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const long long npairs = *tot;
+    if (npairs > cap) return fail(c, VSM_ECAP, "%lld pairs do not fit a buffer of %lld", npairs, cap);
+    if (npairs > 0) {
+        HIPCHK(c, hipMemcpyAsync(pairs, d_pairs, (size_t)npairs * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return npairs;
 }

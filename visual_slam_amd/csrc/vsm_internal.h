@@ -199,6 +199,17 @@ void launch_geom_verify(const GeomPair* pairs, int npairs, int max_matches, cons
                         float* Fout, int32_t* counts, int32_t* slot_i0, int32_t* slot_i1, SiftPair* pack_pairs,
                         hipStream_t s);
 
+// ---- image-pair shortlist from a visual vocabulary ----------------------------------------
+// hist: [nimg][nwords] counts (zeroed by the caller); words / offsets: the tight nearest-row list of a
+// submission whose pair p is (image first_image + p, vocabulary) with every row accepted.
+void launch_bow_count(const int64_t* offsets, const int32_t* words, int first_image, int nimages, int nwords,
+                      uint32_t* hist, hipStream_t s);
+// Weights the histograms in place, fills scores [nimg][nimg], marks (zeroed by the caller, [nimg][nimg]
+// bytes) the pairs chosen by some image's topk, and writes them in ascending (i, j) order: offsets[nimg]
+// is the pair count.
+void launch_bow_shortlist(uint32_t* hist, int nimg, int nwords, int topk, uint32_t* weight, int32_t* scores,
+                          uint8_t* mark, int32_t* counts, int64_t* offsets, int32_t* pairs, hipStream_t s);
+
 void launch_pack(const SiftPair* pairs, int npairs, const int32_t* counts, int64_t* offsets,
                  const int32_t* slot_i0, const int32_t* slot_i1,
                  int32_t* tight_i0, int32_t* tight_i1, hipStream_t s);

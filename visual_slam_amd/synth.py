@@ -113,3 +113,33 @@ def multi_view(nimages, n, seed, shared=0.6, desc_noise=4, pixel_noise=0.4):
         kps.append(kp)
         dess.append(des)
     return kps, dess
+
+
+def image_groups(ngroups, per_group, n, seed, shared=0.5, noise=4.0, dtype="u8", dim=128):
+    """`ngroups * per_group` descriptor sets; the images of one group show one scene: round(shared * n)
+    rows of each are perturbed copies of rows of the group's pool, the rest is clutter.  Groups share
+    nothing.  Returns (list of arrays, group index per image).  dtype "u8" (SIFT-like, 128) or "f32"."""
+    rng = np.random.default_rng(seed)
+    ns = int(round(shared * n))
+    images, group = [], []
+    for g in range(ngroups):
+        pool = sift_like(2 * ns, rng) if dtype == "u8" else unit_f32(2 * ns, dim, rng)
+        for _ in range(per_group):
+            pick = rng.permutation(2 * ns)[:ns]
+            if dtype == "u8":
+                seen = np.clip(pool[pick].astype(np.float32) + rng.normal(0.0, noise, (ns, 128)), 0, 255)
+                img = np.concatenate([np.rint(seen).astype(np.uint8), sift_like(n - ns, rng)])
+            else:
+                seen = pool[pick] + rng.normal(0.0, noise, (ns, dim)).astype(np.float32)
+                seen /= np.linalg.norm(seen, axis=1, keepdims=True).astype(np.float32)
+                img = np.concatenate([seen.astype(np.float32), unit_f32(n - ns, dim, rng)])
+            images.append(np.ascontiguousarray(img[rng.permutation(n)]))
+            group.append(g)
+    return images, np.asarray(group, np.int32)
+
+
+def sample_vocabulary(images, nwords, seed):
+    """`nwords` rows drawn without replacement from the rows of all images: a cheap visual vocabulary."""
+    rng = np.random.default_rng(seed)
+    allrows = np.concatenate(images)
+    return np.ascontiguousarray(allrows[rng.permutation(len(allrows))[:nwords]])
