@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sift_exhaustive",
                     choices=["sift_exhaustive", "superpoint_pair", "superpoint_pairs", "sift_large_pair", "db_query",
-                             "geom_verify"])
+                             "geom_verify", "shortlist"])
     ap.add_argument("--images", type=int, default=1000)
     ap.add_argument("--features", type=int, default=8192)
     ap.add_argument("--pairs-per-step", type=int, default=2048)
@@ -504,6 +504,54 @@ def run_geom_verify(args, torch, dist, world, rank):
     return out
 
 
+def run_shortlist(args, torch, dist, world, rank):
+    """Pair shortlist for the exhaustive workload's collection: 1000 images x 8192 SIFT features, a
+    vocabulary of 4096 words drawn from them, 20 partners per image.  One step = one whole shortlist
+    (word assignment of 8.2 M descriptors, histograms, 1000 x 1000 scores, choices).  Does not shard:
+    with more than one rank every rank computes the same list (replicas only)."""
+    import visual_slam_amd as vsm
+
+    nimg, nfeat, nwords, topk = args.images, args.features, 4096, 20
+    arena = gen_sift_arena(torch, nimg, nfeat, seed=1234)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    pick = torch.randperm(nimg * nfeat, generator=g, device="cuda")[:nwords]
+    vocab = arena.reshape(-1, 128)[pick].contiguous()
+    torch.cuda.synchronize()
+    m = vsm.Matcher(torch.cuda.current_device())
+    ids = [m.upload_u8_device(arena[i].data_ptr(), nfeat) for i in range(nimg)]
+    vid = m.upload_u8_device(vocab.data_ptr(), nwords)
+    m.set_timing(True)
+    for _ in range(args.warmup):
+        m.shortlist_pairs(ids, vid, topk)
+    barrier_sync(torch, dist, world)
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        pairs = m.shortlist_pairs(ids, vid, topk)
+        kernel_ms.append(m.last_kernel_ms())
+    barrier_sync(torch, dist, world)
+    dt = max_over_ranks(torch, dist, world, time.perf_counter() - t0)
+    kms = float(np.mean(kernel_ms))
+    ops = OPS_PER_EVAL_U8 * float(nimg) * nfeat * nwords    # the word assignment; the rest is < 1 % of the work
+    achieved = ops / (kms * 1e-3) / 1e12
+    out = {
+        "metric": "images shortlisted/sec", "value": args.steps * nimg / dt, "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "replicas",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "vocabulary shortlist, %d images x %d SIFT-128 features, %d words, %d partners per image"
+                               % (nimg, nfeat, nwords, topk),
+                   "parallelism": "replicas only", "pairs_listed": int(len(pairs))},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
+                     "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": None, "kernel": "sift_query_kernel",
+                     "kernel_ms": kms,
+                     "note": "kernel_ms = the word-assignment launch (descriptors x words distances)"},
+    }
+    m.close()
+    return out
+
+
 def run_db_query(args, torch, dist, world, rank):
     """16384 float-256 queries against a 1M-row database cut into `world` contiguous slices;
     every rank searches its slice, the per-slice 2-NN lists are all-gathered and merged."""
@@ -577,7 +625,8 @@ def main():
     torch, dist, world, rank, local = dist_setup(args)
     fn = {"sift_exhaustive": run_sift_exhaustive, "superpoint_pair": run_superpoint_pair,
           "superpoint_pairs": run_superpoint_pairs,
-          "sift_large_pair": run_sift_large_pair, "db_query": run_db_query, "geom_verify": run_geom_verify}[args.workload]
+          "sift_large_pair": run_sift_large_pair, "db_query": run_db_query, "geom_verify": run_geom_verify,
+          "shortlist": run_shortlist}[args.workload]
     out = fn(args, torch, dist, world, rank)
     if rank == 0:
         print(json.dumps(out))

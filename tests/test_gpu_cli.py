@@ -146,3 +146,36 @@ def test_sharded_verification_equals_the_unsharded_run(tmp_path):
     assert open(shard_in, "rb").read() == open(whole_in, "rb").read()
     assert open(str(tmp_path / "shard.txt"), "rb").read() == open(str(tmp_path / "whole.txt"), "rb").read()
     assert os.path.getsize(whole_in) > 5000
+
+
+@pytest.mark.parametrize("own_words", [True, False])
+def test_cli_pairs_from_a_vocabulary(tmp_path, own_words):
+    """--pairs vocab: the pair list is the shortlist the oracle computes from the same words (drawn from
+    the images by the driver's rule, or read from a .sift file), and every listed pair is matched."""
+    images, group = synth.image_groups(4, 3, 500, seed=31, shared=0.6)
+    rng = np.random.default_rng(1)
+    for i, des in enumerate(images):
+        host.write_sift(str(tmp_path / ("%d.sift" % i)), rng.random((len(des), 5)).astype(np.float32), des)
+    num, topk, nwords = len(images), 2, 700
+    out = str(tmp_path / "matching.txt")
+    cmd = [CLI, "--sift-dir", str(tmp_path), "--num", str(num), "--out", out, "--pairs", "vocab", "--topk", str(topk)]
+    if own_words:
+        cmd += ["--vocab-size", str(nwords)]
+        words = []
+        for i, des in enumerate(images):
+            q = min(len(des), nwords // num + (1 if i < nwords % num else 0))
+            words += [des[j * len(des) // q] for j in range(q)]
+        vocab = np.asarray(words, np.uint8)
+    else:
+        vocab = synth.sample_vocabulary(images, nwords, seed=32)
+        host.write_sift(str(tmp_path / "words.sift"), np.zeros((nwords, 5), np.float32), vocab)
+        cmd += ["--vocab", str(tmp_path / "words.sift")]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    pairs, _ = orc.shortlist([orc.knn2_u8(img, vocab)[0] for img in images], len(vocab), topk)
+    assert (group[pairs[:, 0]] == group[pairs[:, 1]]).sum() == 4 * 3
+    expect = []
+    for a, b in pairs:
+        m0, _ = orc.match_dense_u8(images[a], images[b], orc.params((4, 5), True))
+        expect.append(orc.matchtxt_record("%d.jpg" % a, "%d.jpg" % b, m0))
+    assert open(out).read() == "".join(expect)

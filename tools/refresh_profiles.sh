@@ -22,6 +22,8 @@ stats superpoint_pair --workload superpoint_pair --steps 50
 stats superpoint_pairs --workload superpoint_pairs
 stats sift_large_pair --workload sift_large_pair
 stats geom_verify --workload geom_verify
+stats shortlist --workload shortlist
+timeout -k 10 300 python3 $root/bench.py --workload shortlist > $out/${tag}_bench_shortlist.json.log 2>/dev/null
 timeout -k 10 300 python3 $root/bench.py --workload geom_verify > $out/${tag}_bench_geom_verify.json.log 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c

@@ -25,6 +25,9 @@ struct Options {
     int num = 0, device = 0, batch = 4096;
     int shard = 0, nshards = 1;
     bool exhaustive = true, mutual = true, write_mat = false, append = false;
+    bool by_vocab = false;        // pair list from a visual vocabulary (vsm_shortlist_pairs)
+    int vocab_size = 4096, topk = 20;
+    std::string vocab_file;       // .sift file whose descriptors are the words; empty: rows drawn from the images
     int consecutive = 3;
     std::vector<int32_t> discrete{7, 15};
     int ratio_num = 4, ratio_den = 5;
@@ -42,7 +45,11 @@ void usage()
             "usage: vsm_match_pairs --sift-dir DIR --num N [options]\n"
             "  --out FILE            match txt to write (default matching.txt)\n"
             "  --append              append to FILE instead of starting it\n"
-            "  --pairs exhaustive|window   all i<j pairs (default) or the reference's window list\n"
+            "  --pairs exhaustive|window|vocab   all i<j pairs (default), the reference's window list, or every\n"
+            "                        image's --topk most similar images by visual-word histograms\n"
+            "  --topk T              vocab list: partners chosen per image (default 20)\n"
+            "  --vocab FILE.sift     vocab list: the words; without it --vocab-size K (default 4096) rows are\n"
+            "                        taken from the images themselves, evenly spread\n"
             "  --consecutive K       window list: pairs (i, i+1..i+K)          (default 3)\n"
             "  --discrete A,B,...    window list: pairs (i, i+A), (i, i+B) ... (default 7,15)\n"
             "  --ratio NUM/DEN       Lowe ratio, exact rational (default 4/5; 0/1 disables)\n"
@@ -76,7 +83,14 @@ bool parse(int argc, char** argv, Options& o)
         else if (a == "--num") { if (!(v = next("--num"))) return false; o.num = atoi(v); }
         else if (a == "--out") { if (!(v = next("--out"))) return false; o.out = v; }
         else if (a == "--append") o.append = true;
-        else if (a == "--pairs") { if (!(v = next("--pairs"))) return false; o.exhaustive = strcmp(v, "window") != 0; }
+        else if (a == "--pairs") {
+            if (!(v = next("--pairs"))) return false;
+            o.by_vocab = strcmp(v, "vocab") == 0;
+            o.exhaustive = !o.by_vocab && strcmp(v, "window") != 0;
+        }
+        else if (a == "--topk") { if (!(v = next("--topk"))) return false; o.topk = atoi(v); }
+        else if (a == "--vocab") { if (!(v = next("--vocab"))) return false; o.vocab_file = v; }
+        else if (a == "--vocab-size") { if (!(v = next("--vocab-size"))) return false; o.vocab_size = atoi(v); }
         else if (a == "--consecutive") { if (!(v = next("--consecutive"))) return false; o.consecutive = atoi(v); }
         else if (a == "--discrete") {
             if (!(v = next("--discrete"))) return false;
@@ -114,7 +128,7 @@ bool parse(int argc, char** argv, Options& o)
         fprintf(stderr, "--inlier-out needs --verify\n");
         return false;
     }
-    return !o.sift_dir.empty() && o.num > 0 && o.batch > 0 && o.samples > 0;
+    return !o.sift_dir.empty() && o.num > 0 && o.batch > 0 && o.samples > 0 && o.topk > 0 && o.vocab_size > 0;
 }
 
 }  // namespace
@@ -137,6 +151,9 @@ int main(int argc, char** argv)
     // time, and uploaded in order by this one
     std::vector<int> set_id(o.num, -1), count(o.num, 0), xy_id(o.num, -1);
     const bool verify = o.verify > 0.0f;
+    // words drawn from the images: vocab_size / num rows of each (one more from the first vocab_size % num), evenly spread
+    const bool draw_words = o.by_vocab && o.vocab_file.empty();
+    std::vector<uint8_t> words;
     {
         const int kChunk = 256;
         const int nthreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
@@ -168,6 +185,13 @@ int main(int argc, char** argv)
                     return 1;
                 }
                 count[i] = np[k];
+                if (draw_words) {
+                    const int q = std::min(np[k], o.vocab_size / o.num + (i < o.vocab_size % o.num ? 1 : 0));
+                    for (int j = 0; j < q; ++j) {
+                        const uint8_t* row = des[k].data() + (size_t)((long long)j * np[k] / q) * VSM_DESC_DIM_U8;
+                        words.insert(words.end(), row, row + VSM_DESC_DIM_U8);
+                    }
+                }
                 set_id[i] = vsm_upload_u8(ctx, des[k].data(), np[k]);
                 if (set_id[i] < 0) {
                     fprintf(stderr, "upload %d%s: %s\n", i, o.sift_ext.c_str(), vsm_last_error(ctx));
@@ -195,7 +219,35 @@ int main(int argc, char** argv)
     // ---- pair list
     std::vector<int32_t> pairs;
     long long npairs;
-    if (o.exhaustive) {
+    if (o.by_vocab) {
+        if (!draw_words) {
+            int n = 0;
+            if (!vsm_sift_read(o.vocab_file.c_str(), nullptr, nullptr, 0, &n, nullptr) || n <= 0) {
+                fprintf(stderr, "cannot read the vocabulary %s\n", o.vocab_file.c_str());
+                return 1;
+            }
+            words.resize((size_t)n * VSM_DESC_DIM_U8);
+            if (!vsm_sift_read(o.vocab_file.c_str(), nullptr, words.data(), n, nullptr, nullptr)) {
+                fprintf(stderr, "short read: %s\n", o.vocab_file.c_str());
+                return 1;
+            }
+        }
+        const int nwords = (int)(words.size() / VSM_DESC_DIM_U8);
+        const int vocab_id = nwords > 0 ? vsm_upload_u8(ctx, words.data(), nwords) : VSM_EINVAL;
+        if (vocab_id < 0) {
+            fprintf(stderr, "vocabulary of %d words: %s\n", nwords, nwords > 0 ? vsm_last_error(ctx) : "no descriptors to draw from");
+            return 1;
+        }
+        const long long cap = std::min<long long>((long long)o.num * std::min(o.topk, o.num), (long long)o.num * (o.num - 1) / 2);
+        pairs.resize((size_t)cap * 2 + 2);
+        npairs = vsm_shortlist_pairs(ctx, set_id.data(), o.num, vocab_id, o.topk, pairs.data(), cap, nullptr);
+        if (npairs < 0) {
+            fprintf(stderr, "vsm_shortlist_pairs: %s\n", vsm_last_error(ctx));
+            return 1;
+        }
+        vsm_release_set(ctx, vocab_id);
+        fprintf(stderr, "vocabulary of %d words, %d partners per image: %lld pairs\n", nwords, o.topk, npairs);
+    } else if (o.exhaustive) {
         npairs = vsm_image_pairs_exhaustive(o.num, nullptr, 0);
         pairs.resize((size_t)npairs * 2 + 2);
         vsm_image_pairs_exhaustive(o.num, pairs.data(), npairs);

@@ -30,22 +30,27 @@ __global__ __launch_bounds__(256) void bow_count_kernel(const int64_t* __restric
     }
 }
 
-// weight[w] = 0 for a word no image holds, else 1 + floor(log2(nimg / df)) with the integer quotient.
-__global__ __launch_bounds__(256) void bow_weight_kernel(const uint32_t* __restrict__ hist, int nimg, int nwords,
-                                                         uint32_t* __restrict__ weight)
+// df[w] = number of images that hold word w (zeroed by the caller); grid (words / 256, slices of 32 images).
+__global__ __launch_bounds__(256) void bow_df_kernel(const uint32_t* __restrict__ hist, int nimg, int nwords,
+                                                     uint32_t* __restrict__ df)
 {
     const int w = blockIdx.x * 256 + threadIdx.x;
     if (w >= nwords) return;
-    int df = 0;
-    for (int i = 0; i < nimg; ++i) df += hist[(size_t)i * nwords + w] != 0u;
-    weight[w] = df ? (uint32_t)(32 - __clz(nimg / df)) : 0u;
+    const int i0 = blockIdx.y * 32, i1 = min(i0 + 32, nimg);
+    uint32_t n = 0;
+    for (int i = i0; i < i1; ++i) n += hist[(size_t)i * nwords + w] != 0u;
+    if (n) atomicAdd(&df[w], n);
 }
 
-__global__ __launch_bounds__(256) void bow_scale_kernel(uint32_t* __restrict__ hist, const uint32_t* __restrict__ weight,
-                                                        int nwords, size_t total)
+// weight[w] = 0 for a word no image holds, else 1 + floor(log2(nimg / df)) with the integer quotient;
+// the histograms are weighted in place (weight * min(a, b) = min(weight * a, weight * b)).
+__global__ __launch_bounds__(256) void bow_scale_kernel(uint32_t* __restrict__ hist, const uint32_t* __restrict__ df,
+                                                        int nimg, int nwords, size_t total)
 {
-    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (size_t)gridDim.x * 256)
-        hist[k] *= weight[k % (size_t)nwords];
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (size_t)gridDim.x * 256) {
+        const uint32_t d = df[k % (size_t)nwords];
+        hist[k] *= d ? (uint32_t)(32 - __clz(nimg / (int)d)) : 0u;
+    }
 }
 
 // scores[i][j] = sum over words of min(g[i][w], g[j][w]) for the weighted histograms g; tiles on and
@@ -55,8 +60,8 @@ __global__ __launch_bounds__(256) void bow_score_kernel(const uint32_t* __restri
 {
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj < bi) return;
-    __shared__ uint32_t sa[kScoreStep][kScoreTile + 1];
-    __shared__ uint32_t sb[kScoreStep][kScoreTile + 1];
+    __shared__ __align__(16) uint32_t sa[kScoreStep][kScoreTile + 4];   // rows of 68 words: 16-byte reads stay aligned
+    __shared__ __align__(16) uint32_t sb[kScoreStep][kScoreTile + 4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int kk = tid & 31, r0 = tid >> 5;
     uint32_t acc[4][4];
@@ -75,12 +80,9 @@ __global__ __launch_bounds__(256) void bow_score_kernel(const uint32_t* __restri
         __syncthreads();
 #pragma unroll 8
         for (int k = 0; k < kScoreStep; ++k) {
-            uint32_t va[4], vb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                va[u] = sa[k][ty * 4 + u];
-                vb[u] = sb[k][tx * 4 + u];
-            }
+            const uint4 qa = *reinterpret_cast<const uint4*>(&sa[k][ty * 4]);
+            const uint4 qb = *reinterpret_cast<const uint4*>(&sb[k][tx * 4]);
+            const uint32_t va[4] = {qa.x, qa.y, qa.z, qa.w}, vb[4] = {qb.x, qb.y, qb.z, qb.w};
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -229,9 +231,10 @@ void launch_bow_shortlist(uint32_t* hist, int nimg, int nwords, int topk, uint32
 {
     if (nimg <= 0) return;
     const size_t total = (size_t)nimg * nwords;
-    hipLaunchKernelGGL(bow_weight_kernel, dim3((nwords + 255) / 256), dim3(256), 0, s, hist, nimg, nwords, weight);
+    (void)hipMemsetAsync(weight, 0, (size_t)nwords * 4, s);
+    hipLaunchKernelGGL(bow_df_kernel, dim3((nwords + 255) / 256, (nimg + 31) / 32), dim3(256), 0, s, hist, nimg, nwords, weight);
     const unsigned sblocks = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
-    hipLaunchKernelGGL(bow_scale_kernel, dim3(sblocks), dim3(256), 0, s, hist, weight, nwords, total);
+    hipLaunchKernelGGL(bow_scale_kernel, dim3(sblocks), dim3(256), 0, s, hist, weight, nimg, nwords, total);
     const int tiles = (nimg + kScoreTile - 1) / kScoreTile;
     hipLaunchKernelGGL(bow_score_kernel, dim3(tiles, tiles), dim3(256), 0, s, hist, nimg, nwords, scores);
     hipLaunchKernelGGL(bow_topk_kernel, dim3(nimg), dim3(256), 0, s, scores, nimg, topk, mark);

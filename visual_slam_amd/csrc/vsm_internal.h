@@ -207,7 +207,7 @@ void launch_bow_count(const int64_t* offsets, const int32_t* words, int first_im
 // Weights the histograms in place, fills scores [nimg][nimg], marks (zeroed by the caller, [nimg][nimg]
 // bytes) the pairs chosen by some image's topk, and writes them in ascending (i, j) order: offsets[nimg]
 // is the pair count.
-void launch_bow_shortlist(uint32_t* hist, int nimg, int nwords, int topk, uint32_t* weight, int32_t* scores,
+void launch_bow_shortlist(uint32_t* hist, int nimg, int nwords, int topk, uint32_t* df, int32_t* scores,
                           uint8_t* mark, int32_t* counts, int64_t* offsets, int32_t* pairs, hipStream_t s);
 
 void launch_pack(const SiftPair* pairs, int npairs, const int32_t* counts, int64_t* offsets,
