@@ -83,3 +83,20 @@ def test_rejects_bad_arguments(matcher):
     assert len(matcher.shortlist_pairs([], a, 2)) == 0
     # the context still works afterwards
     assert len(matcher.shortlist_pairs([a, a], a, 1)) == 1
+
+
+def test_vocabulary_larger_than_the_lds_histogram(matcher):
+    rng = np.random.default_rng(8)
+    images = [synth.sift_like(300, rng) for _ in range(5)]
+    images[3] = images[1].copy()
+    vocab = synth.sift_like(17000, rng)
+    vocab[:15000:50] = images[1]           # 300 words that are hit exactly
+    pairs = _check(matcher, images, vocab, 1)
+    assert [1, 3] in pairs.tolist()
+
+
+def test_thousands_of_small_images(matcher):
+    rng = np.random.default_rng(9)
+    vocab = synth.sift_like(40, rng)
+    images = [synth.sift_like(int(rng.integers(1, 9)), rng) for _ in range(4100)]
+    _check(matcher, images, vocab, 3)

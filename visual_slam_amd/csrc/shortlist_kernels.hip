@@ -42,6 +42,27 @@ __global__ __launch_bounds__(256) void bow_df_kernel(const uint32_t* __restrict_
     if (n) atomicAdd(&df[w], n);
 }
 
+// The same with the histogram of an image in LDS (vocabularies of at most kLdsWords words): one
+// workgroup per image, plain stores of the finished row.
+constexpr int kLdsWords = 16384;
+__global__ __launch_bounds__(1024) void bow_count_lds_kernel(const int64_t* __restrict__ offsets,
+                                                             const int32_t* __restrict__ words, int first_image,
+                                                             int nwords, uint32_t* __restrict__ hist)
+{
+    extern __shared__ uint32_t s_hist[];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    for (int w = tid; w < nwords; w += 1024) s_hist[w] = 0u;
+    __syncthreads();
+    const int64_t lo = offsets[p], hi = offsets[p + 1];
+    for (int64_t r = lo + tid; r < hi; r += 1024) {
+        const int w = words[r];
+        if (w >= 0 && w < nwords) atomicAdd(&s_hist[w], 1u);
+    }
+    __syncthreads();
+    uint32_t* h = hist + (size_t)(first_image + p) * nwords;
+    for (int w = tid; w < nwords; w += 1024) h[w] = s_hist[w];
+}
+
 // weight[w] = 0 for a word no image holds, else 1 + floor(log2(nimg / df)) with the integer quotient;
 // the histograms are weighted in place (weight * min(a, b) = min(weight * a, weight * b)).
 __global__ __launch_bounds__(256) void bow_scale_kernel(uint32_t* __restrict__ hist, const uint32_t* __restrict__ df,
@@ -54,12 +75,15 @@ __global__ __launch_bounds__(256) void bow_scale_kernel(uint32_t* __restrict__ h
 }
 
 // scores[i][j] = sum over words of min(g[i][w], g[j][w]) for the weighted histograms g; tiles on and
-// above the diagonal are computed and written to both triangles.
+// above the diagonal are computed and added to both triangles.  blockIdx.z takes a slice of
+// words_per_slice words (a multiple of kScoreStep), so that a few hundred images still give the chip
+// enough workgroups; the slices meet in integer atomic adds on scores, which the caller has zeroed.
 __global__ __launch_bounds__(256) void bow_score_kernel(const uint32_t* __restrict__ g, int nimg, int nwords,
-                                                        int32_t* __restrict__ scores)
+                                                        int words_per_slice, int32_t* __restrict__ scores)
 {
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj < bi) return;
+    const int k_lo = blockIdx.z * words_per_slice, k_hi = min(nwords, k_lo + words_per_slice);
     __shared__ __align__(16) uint32_t sa[kScoreStep][kScoreTile + 4];   // rows of 68 words: 16-byte reads stay aligned
     __shared__ __align__(16) uint32_t sb[kScoreStep][kScoreTile + 4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -69,8 +93,8 @@ __global__ __launch_bounds__(256) void bow_score_kernel(const uint32_t* __restri
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0u;
-    for (int k0 = 0; k0 < nwords; k0 += kScoreStep) {
-        const bool kin = k0 + kk < nwords;
+    for (int k0 = k_lo; k0 < k_hi; k0 += kScoreStep) {
+        const bool kin = k0 + kk < k_hi;
 #pragma unroll
         for (int r = r0; r < kScoreTile; r += 8) {
             const int ia = bi * kScoreTile + r, ib = bj * kScoreTile + r;
@@ -95,9 +119,9 @@ __global__ __launch_bounds__(256) void bow_score_kernel(const uint32_t* __restri
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int i = bi * kScoreTile + ty * 4 + a, j = bj * kScoreTile + tx * 4 + b;
-            if (i < nimg && j < nimg) {
-                scores[(size_t)i * nimg + j] = (int32_t)acc[a][b];
-                scores[(size_t)j * nimg + i] = (int32_t)acc[a][b];
+            if (i < nimg && j < nimg && acc[a][b] != 0u) {
+                atomicAdd(&scores[(size_t)i * nimg + j], (int32_t)acc[a][b]);
+                if (bi != bj) atomicAdd(&scores[(size_t)j * nimg + i], (int32_t)acc[a][b]);   // a diagonal tile holds both (i, j) and (j, i) itself
             }
         }
 }
@@ -223,7 +247,11 @@ void launch_bow_count(const int64_t* offsets, const int32_t* words, int first_im
                       uint32_t* hist, hipStream_t s)
 {
     if (nimages <= 0) return;
-    hipLaunchKernelGGL(bow_count_kernel, dim3(32, nimages), dim3(256), 0, s, offsets, words, first_image, nwords, hist);
+    if (nwords <= kLdsWords)
+        hipLaunchKernelGGL(bow_count_lds_kernel, dim3(nimages), dim3(1024), (size_t)nwords * 4, s, offsets, words,
+                           first_image, nwords, hist);
+    else
+        hipLaunchKernelGGL(bow_count_kernel, dim3(32, nimages), dim3(256), 0, s, offsets, words, first_image, nwords, hist);
 }
 
 void launch_bow_shortlist(uint32_t* hist, int nimg, int nwords, int topk, uint32_t* weight, int32_t* scores,
@@ -236,7 +264,12 @@ void launch_bow_shortlist(uint32_t* hist, int nimg, int nwords, int topk, uint32
     const unsigned sblocks = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
     hipLaunchKernelGGL(bow_scale_kernel, dim3(sblocks), dim3(256), 0, s, hist, weight, nimg, nwords, total);
     const int tiles = (nimg + kScoreTile - 1) / kScoreTile;
-    hipLaunchKernelGGL(bow_score_kernel, dim3(tiles, tiles), dim3(256), 0, s, hist, nimg, nwords, scores);
+    const int upper = tiles * (tiles + 1) / 2, steps = (nwords + kScoreStep - 1) / kScoreStep;
+    const int nslices = std::max(1, std::min({(2048 + upper - 1) / upper, steps, 1024}));
+    const int words_per_slice = (steps + nslices - 1) / nslices * kScoreStep;
+    (void)hipMemsetAsync(scores, 0, (size_t)nimg * nimg * 4, s);
+    hipLaunchKernelGGL(bow_score_kernel, dim3(tiles, tiles, (nwords + words_per_slice - 1) / words_per_slice), dim3(256), 0, s,
+                       hist, nimg, nwords, words_per_slice, scores);
     hipLaunchKernelGGL(bow_topk_kernel, dim3(nimg), dim3(256), 0, s, scores, nimg, topk, mark);
     hipLaunchKernelGGL(bow_rowcount_kernel, dim3(nimg), dim3(256), 0, s, mark, nimg, counts);
     hipLaunchKernelGGL(bow_offsets_kernel, dim3(1), dim3(1024), 0, s, counts, nimg, offsets);
