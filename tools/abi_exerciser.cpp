@@ -121,6 +121,15 @@ int main()
         std::vector<float> res((size_t)batch * dim * npts);
         CHECK(vsm_nearest_embed(ctx, x.data(), batch, dim, npts, emb.data(), k, arg.data(), res.data()));
     }
+    {   // pair shortlist over u8 sets (one of them empty) with a small vocabulary, with and without the score matrix
+        auto words = bytes(37);
+        const int vs = vsm_upload_u8(ctx, words.data(), 37);
+        CHECK(vs);
+        const int32_t imgs[] = {s0, s1, se, s0};
+        std::vector<int32_t> sp(2 * 6), sc(16);
+        CHECK(vsm_shortlist_pairs(ctx, imgs, 4, vs, 2, sp.data(), 6, sc.data()));
+        CHECK(vsm_shortlist_pairs(ctx, imgs, 4, vs, 1, sp.data(), 6, nullptr));
+    }
     printf("kernel ms %.3f, verify ms %.3f, last pairs %d\n", vsm_last_kernel_ms(ctx), vsm_last_verify_ms(ctx), vsm_last_submission_pairs(ctx));
     vsm_destroy(ctx);
     puts("abi exerciser done");
