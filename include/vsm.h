@@ -241,6 +241,14 @@ long long vsm_image_pairs_exhaustive(int nimages, int32_t* pairs, long long cap)
  * the [nimg][nimg] score matrix.  All integer arithmetic.  Returns the pair count. */
 long long vsm_shortlist_pairs(vsm_ctx* ctx, const int32_t* sets, int nimg, int vocab_set, int topk,
                               int32_t* pairs, long long cap, int32_t* scores);
+/* A vocabulary for vsm_shortlist_pairs by k-means over all rows of the resident u8 sets (no counterpart in
+ * the reference either; NearestEmbed's codebook, model_2_0.py:84-103, is learned by gradient descent).
+ * K = min(nwords, total rows); word k starts as row floor(k * total / K) of the concatenation of the
+ * sets; every iteration assigns each row to its nearest word (squared L2, lowest word among equals) and
+ * replaces each word by the mean of its rows, per component (2 * sum + count) / (2 * count) in integers;
+ * a word without rows keeps its value.  words receives K rows of 128 bytes.  Returns K. */
+int vsm_train_vocabulary(vsm_ctx* ctx, const int32_t* sets, int nimg, int nwords, int iterations,
+                         uint8_t* words);
 /* MatchFile::WritePMatch(image1, image2, fc1, fc2, NM, matches) (MatchFile.cpp:751-832):
  * image paths without extension; writes <image1>.mat and <image2>.mat.
  * reservation = MatchFile::SetRecordReservation (MatchFile.h:244); pass 0 for the

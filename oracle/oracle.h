@@ -91,6 +91,9 @@ void orc_merge_top2_f32(const float* k1, const float* k2, const int32_t* i1, con
 long long orc_shortlist(const int32_t* words, const int64_t* offsets, int nimg, int nwords, int topk,
                         int32_t* pairs, long long cap, int32_t* scores);
 
+int orc_train_vocabulary(const uint8_t* rows, long long total, int nwords, int iterations, int threads,
+                         uint8_t* words);
+
 /* ---- formats ---------------------------------------------------------------- */
 /* FeaturePoints.cpp:228-280 / :388-446.  Returns bytes written or <0. */
 long orc_sift_write(const char* path, const float* loc, int nloc_dim,

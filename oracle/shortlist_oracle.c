@@ -89,3 +89,43 @@ long long orc_shortlist(const int32_t* words, const int64_t* offsets, int nimg, 
     free(taken);
     return n;
 }
+
+/* k-means vocabulary over rows[total][128] (the concatenation of the images' descriptors): word k starts
+ * as row floor(k * total / K), K = min(nwords, total); every iteration assigns each row to its nearest
+ * word (orc_knn2_u8: squared L2, lowest word among equals) and replaces each word by the rounded mean of
+ * its rows, (2 * sum + count) / (2 * count) per component; a word without rows keeps its value.
+ * Returns K. */
+int orc_train_vocabulary(const uint8_t* rows, long long total, int nwords, int iterations, int threads,
+                         uint8_t* words)
+{
+    if (total <= 0 || nwords < 1) return 0;
+    const int K = (int)(nwords < total ? nwords : total);
+    for (int k = 0; k < K; ++k) {
+        const long long g = (long long)(((__int128)k * total) / K);
+        memcpy(words + (size_t)k * 128, rows + (size_t)g * 128, 128);
+    }
+    int32_t* idx = (int32_t*)malloc((size_t)total * sizeof(int32_t));
+    int32_t* d1 = (int32_t*)malloc((size_t)total * sizeof(int32_t));
+    int32_t* d2 = (int32_t*)malloc((size_t)total * sizeof(int32_t));
+    uint64_t* sums = (uint64_t*)malloc((size_t)K * 128 * sizeof(uint64_t));
+    uint64_t* counts = (uint64_t*)malloc((size_t)K * sizeof(uint64_t));
+    for (int it = 0; it < iterations; ++it) {
+        orc_knn2_u8(rows, (int)total, words, K, threads, idx, d1, d2);
+        memset(sums, 0, (size_t)K * 128 * sizeof(uint64_t));
+        memset(counts, 0, (size_t)K * sizeof(uint64_t));
+        for (long long r = 0; r < total; ++r) {
+            counts[idx[r]] += 1;
+            for (int k = 0; k < 128; ++k) sums[(size_t)idx[r] * 128 + k] += rows[(size_t)r * 128 + k];
+        }
+        for (int w = 0; w < K; ++w)
+            if (counts[w])
+                for (int k = 0; k < 128; ++k)
+                    words[(size_t)w * 128 + k] = (uint8_t)((2 * sums[(size_t)w * 128 + k] + counts[w]) / (2 * counts[w]));
+    }
+    free(idx);
+    free(d1);
+    free(d2);
+    free(sums);
+    free(counts);
+    return K;
+}

@@ -225,3 +225,13 @@ def shortlist(words_per_image, nwords, topk):
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
     n = fn(_p(words), _p(off), nimg, int(nwords), int(topk), _p(pairs), cap, _p(scores))
     return pairs[:n], scores[:nimg, :nimg]
+
+
+def train_vocabulary(images, nwords, iterations, threads=THREADS):
+    rows = np.ascontiguousarray(np.concatenate([np.asarray(i, np.uint8).reshape(-1, 128) for i in images]))
+    words = np.empty((max(int(nwords), 1), 128), np.uint8)
+    fn = lib().orc_train_vocabulary
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    k = fn(_p(rows), len(rows), int(nwords), int(iterations), threads, _p(words))
+    return words[:k]

@@ -100,3 +100,30 @@ def test_thousands_of_small_images(matcher):
     vocab = synth.sift_like(40, rng)
     images = [synth.sift_like(int(rng.integers(1, 9)), rng) for _ in range(4100)]
     _check(matcher, images, vocab, 3)
+
+
+@pytest.mark.parametrize("sizes,nwords,iterations", [([300, 0, 200, 513], 50, 0), ([300, 0, 200, 513], 50, 4),
+                                                      ([40], 100, 3), ([700] * 6, 257, 6), ([5, 3], 1, 2)])
+def test_trained_vocabulary_equals_the_oracle(matcher, sizes, nwords, iterations):
+    rng = np.random.default_rng(sum(sizes) + nwords)
+    pool = synth.sift_like(150, rng)
+    images = []
+    for n in sizes:
+        img = synth.sift_like(n, rng)
+        k = n // 2          # half of every image: noisy copies of a few pool rows, so that words attract many rows
+        img[:k] = np.clip(pool[rng.integers(0, 150, k)].astype(np.int32) + rng.integers(-4, 5, (k, 128)), 0, 255)
+        images.append(img)
+    ids = [matcher.upload_u8(img) for img in images]
+    try:
+        words = matcher.train_vocabulary(ids, nwords, iterations)
+    finally:
+        for s in ids:
+            matcher.release(s)
+    np.testing.assert_array_equal(words, orc.train_vocabulary(images, nwords, iterations))
+
+
+def test_train_vocabulary_rejects_float_sets(matcher):
+    f = matcher.upload_f32(synth.unit_f32(10, 256, np.random.default_rng(1)))
+    with pytest.raises(vsm.VsmError):
+        matcher.train_vocabulary([f], 4, 1)
+    assert len(matcher.train_vocabulary([], 4, 1)) == 0

@@ -46,3 +46,17 @@ def test_images_of_one_scene_choose_each_other():
     same = group[pairs[:, 0]] == group[pairs[:, 1]]
     assert same.sum() == 6 * 6          # every pair inside a group of four is there
     assert same.mean() > 0.9            # and little else
+
+
+def test_trained_vocabulary_lowers_the_quantisation_error():
+    images, _ = synth.image_groups(3, 3, 200, seed=6, shared=0.6)
+    rows = np.concatenate(images)
+
+    def cost(words):
+        return int(orc.knn2_u8(rows, words)[1].astype(np.int64).sum())
+
+    w0 = orc.train_vocabulary(images, 64, 0)
+    w5 = orc.train_vocabulary(images, 64, 5)
+    np.testing.assert_array_equal(w0, rows[[k * len(rows) // 64 for k in range(64)]])
+    assert w5.shape == (64, 128) and cost(w5) < 0.8 * cost(w0)
+    assert len(orc.train_vocabulary(images[:1], 1000, 2)) == 200     # no more words than rows

@@ -90,6 +90,7 @@ SIGNATURES = {
     "vsm_matchtxt_close": (C.c_int, [C.c_void_p]),
     "vsm_image_pairs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "vsm_image_pairs_exhaustive": (C.c_longlong, [C.c_int, C.c_void_p, C.c_longlong]),
+    "vsm_train_vocabulary": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vsm_shortlist_pairs": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong,
                                            C.c_void_p]),
     "vsm_mat_write_pmatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
@@ -338,6 +339,14 @@ class Matcher:
         got = self._check(self._l.vsm_shortlist_pairs(self._h, _ptr(sets), n, int(vocab_set), int(topk), _ptr(pairs),
                                                       cap, _ptr(scores)))
         return (pairs[:got], scores) if want_scores else pairs[:got]
+
+    def train_vocabulary(self, sets, nwords, iterations=10):
+        """k-means vocabulary over all rows of the resident u8 sets: uint8 [K, 128], K = min(nwords, rows)."""
+        sets = np.ascontiguousarray(sets, dtype=np.int32).reshape(-1)
+        words = np.empty((max(int(nwords), 1), 128), np.uint8)
+        k = self._check(self._l.vsm_train_vocabulary(self._h, _ptr(sets), sets.shape[0], int(nwords), int(iterations),
+                                                     _ptr(words)))
+        return words[:k]
 
     # ---- geometric verification ---------------------------------------------------------
     def upload_xy(self, xy):

@@ -241,7 +241,83 @@ __global__ __launch_bounds__(1024) void bow_emit_kernel(const uint8_t* __restric
     }
 }
 
+// ---- vocabulary training (Lloyd iterations on u8 descriptors, integers only) ----------------------
+
+// byte k of row r of a fragment-major int8 set, as the u8 it was uploaded as
+__device__ __forceinline__ unsigned frag_byte(const int8_t* __restrict__ frag, int r, int k)
+{
+    const size_t o = (size_t)(r >> 5) * kTileBytes + (size_t)(k >> 5) * 1024 + (size_t)((((k >> 4) & 1) * 32 + (r & 31)) * 16) + (k & 15);
+    return (unsigned)(uint8_t)frag[o] ^ 0x80u;
+}
+
+// One wave per word: the row picked as its first value.
+__global__ __launch_bounds__(256) void kmeans_seed_kernel(const int8_t* const* __restrict__ frags,
+                                                          const int32_t* __restrict__ rows, int nwords,
+                                                          uint8_t* __restrict__ words)
+{
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= nwords) return;
+    const int8_t* frag = frags[w];
+    const int r = rows[w];
+    words[(size_t)w * kDescDim + lane] = (uint8_t)frag_byte(frag, r, lane);
+    words[(size_t)w * kDescDim + 64 + lane] = (uint8_t)frag_byte(frag, r, 64 + lane);
+}
+
+// One wave per descriptor row: adds the row to the sums of its word.  Pair p of the submission is
+// (image, vocabulary) with every row accepted, so words[offsets[p] + r] is the word of row r.
+__global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const SiftPair* __restrict__ pairs,
+                                                                const int64_t* __restrict__ offsets,
+                                                                const int32_t* __restrict__ words, int nwords,
+                                                                unsigned long long* __restrict__ sums,
+                                                                unsigned* __restrict__ counts)
+{
+    const int p = blockIdx.y, lane = threadIdx.x & 63;
+    const int8_t* __restrict__ frag = pairs[p].fragA;
+    const int n = pairs[p].nA;
+    const int64_t off = offsets[p];
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += gridDim.x * 4) {
+        const int w = words[off + r];
+        if (w < 0 || w >= nwords) continue;
+        atomicAdd(&sums[(size_t)w * kDescDim + lane], (unsigned long long)frag_byte(frag, r, lane));
+        atomicAdd(&sums[(size_t)w * kDescDim + 64 + lane], (unsigned long long)frag_byte(frag, r, 64 + lane));
+        if (lane == 0) atomicAdd(&counts[w], 1u);
+    }
+}
+
+// word = round-half-up of the mean of its rows; a word without rows keeps its value.
+__global__ __launch_bounds__(256) void kmeans_update_kernel(const unsigned long long* __restrict__ sums,
+                                                            const unsigned* __restrict__ counts, int nwords,
+                                                            uint8_t* __restrict__ words)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= (size_t)nwords * kDescDim) return;
+    const unsigned long long c = counts[k / kDescDim];
+    if (c) words[k] = (uint8_t)((2ull * sums[k] + c) / (2ull * c));
+}
+
 }  // namespace
+
+void launch_kmeans_seed(const int8_t* const* frags, const int32_t* rows, int nwords, uint8_t* words, hipStream_t s)
+{
+    if (nwords <= 0) return;
+    hipLaunchKernelGGL(kmeans_seed_kernel, dim3((nwords + 3) / 4), dim3(256), 0, s, frags, rows, nwords, words);
+}
+
+void launch_kmeans_accumulate(const SiftPair* pairs, int nimages, const int64_t* offsets, const int32_t* words,
+                              int nwords, unsigned long long* sums, unsigned* counts, hipStream_t s)
+{
+    if (nimages <= 0) return;
+    hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3(64, nimages), dim3(256), 0, s, pairs, offsets, words, nwords,
+                       sums, counts);
+}
+
+void launch_kmeans_update(const unsigned long long* sums, const unsigned* counts, int nwords, uint8_t* words,
+                          hipStream_t s)
+{
+    if (nwords <= 0) return;
+    const size_t total = (size_t)nwords * kDescDim;
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sums, counts, nwords, words);
+}
 
 void launch_bow_count(const int64_t* offsets, const int32_t* words, int first_image, int nimages, int nwords,
                       uint32_t* hist, hipStream_t s)

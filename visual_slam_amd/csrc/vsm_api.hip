@@ -1667,6 +1667,45 @@ extern "C" int vsm_nearest_embed(vsm_ctx* c, const float* x, int batch, int dim,
 // ---------------------------------------------------------------------------------
 // image-pair shortlist from a visual vocabulary
 // ---------------------------------------------------------------------------------
+
+namespace {
+
+// Nearest vocabulary row of every descriptor row of sets[0..nimg): submissions of (image, vocabulary)
+// pairs with every test off; after each one `use(first image, images, result slot)` queues the caller's
+// kernels on the lists (pair p of the slot = image first + p, d_tight1 = the word of every row in order).
+template <class Use>
+int assign_words(vsm_ctx* c, const int32_t* sets, int nimg, int vocab_set, Use use)
+{
+    vsm_params prm{};
+    prm.ratio_num = 0; prm.ratio_den = 1; prm.mutual = 0;
+    prm.max_dist_sq = -1; prm.min_score = -INFINITY; prm.max_dist_sq_f = -1.0f;
+    const int64_t rows_per_group = (int64_t)std::max<size_t>(c->scratch_budget / (4 * kScratchPerRow), 1);
+    std::vector<int32_t> pl;
+    for (int g0 = 0; g0 < nimg;) {
+        pl.clear();
+        int64_t rows = 0;
+        int g1 = g0;
+        while (g1 < nimg && g1 - g0 < 4096) {
+            const int n = get_set(c, sets[g1])->n;
+            if (g1 > g0 && rows + n > rows_per_group) break;
+            rows += n;
+            pl.push_back(sets[g1]);
+            pl.push_back(vocab_set);
+            ++g1;
+        }
+        const long long got = vsm_match_pairs_device(c, pl.data(), g1 - g0, &prm, VSM_METRIC_L2);
+        if (got < 0) return (int)got;
+        if (got != rows) return fail(c, VSM_ENODEV, "internal: %lld word assignments for %lld rows", got, (long long)rows);
+        use(g0, g1 - g0, c->slots[c->last_slot]);
+        g0 = g1;
+    }
+    c->last_npairs = 0;   // the resident lists were an intermediate
+    c->last_total = 0;
+    return VSM_OK;
+}
+
+}  // namespace
+
 extern "C" long long vsm_shortlist_pairs(vsm_ctx* c, const int32_t* sets, int nimg, int vocab_set, int topk,
                                          int32_t* pairs, long long cap, int32_t* scores)
 {
@@ -1706,33 +1745,10 @@ extern "C" long long vsm_shortlist_pairs(vsm_ctx* c, const int32_t* sets, int ni
     int32_t* d_pairs = reinterpret_cast<int32_t*>(w); w += b_pairs;
     HIPCHK(c, hipMemsetAsync(d_hist, 0, b_hist, c->stream));
     HIPCHK(c, hipMemsetAsync(d_mark, 0, b_mark, c->stream));
-    // nearest vocabulary row of every descriptor row: submissions of (image, vocabulary) pairs with every test off
-    vsm_params prm{};
-    prm.ratio_num = 0; prm.ratio_den = 1; prm.mutual = 0;
-    prm.max_dist_sq = -1; prm.min_score = -INFINITY; prm.max_dist_sq_f = -1.0f;
-    const int64_t rows_per_group = (int64_t)std::max<size_t>(c->scratch_budget / (4 * kScratchPerRow), 1);
-    std::vector<int32_t> pl;
-    for (int g0 = 0; g0 < nimg;) {
-        pl.clear();
-        int64_t rows = 0;
-        int g1 = g0;
-        while (g1 < nimg && g1 - g0 < 4096) {
-            const int n = get_set(c, sets[g1])->n;
-            if (g1 > g0 && rows + n > rows_per_group) break;
-            rows += n;
-            pl.push_back(sets[g1]);
-            pl.push_back(vocab_set);
-            ++g1;
-        }
-        const long long got = vsm_match_pairs_device(c, pl.data(), g1 - g0, &prm, VSM_METRIC_L2);
-        if (got < 0) return got;
-        if (got != rows) return fail(c, VSM_ENODEV, "internal: %lld word assignments for %lld rows", got, (long long)rows);
-        const vsm_ctx::ResultSlot& R = c->slots[c->last_slot];
-        launch_bow_count(R.d_offsets.as<int64_t>(), R.d_tight1.as<int32_t>(), g0, g1 - g0, K, d_hist, c->stream);
-        g0 = g1;
-    }
-    c->last_npairs = 0;   // the resident lists were an intermediate of this call
-    c->last_total = 0;
+    int rc = assign_words(c, sets, nimg, vocab_set, [&](int g0, int m, const vsm_ctx::ResultSlot& R) {
+        launch_bow_count(R.d_offsets.as<int64_t>(), R.d_tight1.as<int32_t>(), g0, m, K, d_hist, c->stream);
+    });
+    if (rc != VSM_OK) return rc;
     launch_bow_shortlist(d_hist, nimg, K, std::min(topk, nimg), d_w, d_sc, d_mark, d_cnt, d_off, d_pairs, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, c->h_small.ensure(64));
@@ -1747,4 +1763,68 @@ extern "C" long long vsm_shortlist_pairs(vsm_ctx* c, const int32_t* sets, int ni
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return npairs;
+}
+
+extern "C" int vsm_train_vocabulary(vsm_ctx* c, const int32_t* sets, int nimg, int nwords, int iterations,
+                                    uint8_t* words)
+{
+    if (!c) return VSM_EINVAL;
+    if (nimg < 0 || (nimg > 0 && !sets) || nwords < 1 || iterations < 0 || !words) return fail(c, VSM_EINVAL, "bad argument");
+    if (c->inflight) return fail(c, VSM_EINVAL, "collect the submissions in flight first");
+    int64_t total = 0;
+    for (int i = 0; i < nimg; ++i) {
+        const DescSet* A = get_set(c, sets[i]);
+        if (!A || A->kind != SET_U8) return fail(c, VSM_EINVAL, "image %d (set %d) is not a u8 descriptor set", i, sets[i]);
+        total += A->n;
+    }
+    if (total == 0) return 0;
+    const int K = (int)std::min<int64_t>(nwords, total);
+    HIPCHK(c, hipSetDevice(c->device));
+    // first values: rows floor(k * total / K) of the concatenation of the sets, k = 0 .. K-1
+    std::vector<const int8_t*> frags(K);
+    std::vector<int32_t> rows(K);
+    {
+        int img = 0;
+        int64_t first = 0;   // global index of row 0 of image img
+        for (int k = 0; k < K; ++k) {
+            const int64_t g = (int64_t)(((__int128)k * total) / K);
+            while (g >= first + get_set(c, sets[img])->n) first += get_set(c, sets[img++])->n;
+            frags[k] = static_cast<const int8_t*>(get_set(c, sets[img])->frag);
+            rows[k] = (int32_t)(g - first);
+        }
+    }
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_words = up((size_t)K * kDescDim), b_sums = up((size_t)K * kDescDim * 8), b_cnt = up((size_t)K * 4);
+    const size_t b_frags = up((size_t)K * sizeof(void*)), b_rows = up((size_t)K * 4);
+    HIPCHK(c, c->d_short.ensure(b_words + b_sums + b_cnt + b_frags + b_rows));
+    char* w = c->d_short.as<char>();
+    uint8_t* d_words = reinterpret_cast<uint8_t*>(w); w += b_words;
+    unsigned long long* d_sums = reinterpret_cast<unsigned long long*>(w); w += b_sums;
+    unsigned* d_cnt = reinterpret_cast<unsigned*>(w); w += b_cnt;
+    const int8_t** d_frags = reinterpret_cast<const int8_t**>(w); w += b_frags;
+    int32_t* d_rows = reinterpret_cast<int32_t*>(w); w += b_rows;
+    HIPCHK(c, hipMemcpyAsync(d_frags, frags.data(), (size_t)K * sizeof(void*), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_rows, rows.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
+    launch_kmeans_seed(d_frags, d_rows, K, d_words, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // frags and rows are host memory of this call
+    for (int it = 0; it < iterations; ++it) {
+        const int vocab = vsm_upload_u8_device(c, d_words, K);
+        if (vocab < 0) return vocab;
+        HIPCHK(c, hipMemsetAsync(d_sums, 0, b_sums + b_cnt, c->stream));
+        const int rc = assign_words(c, sets, nimg, vocab, [&](int, int m, const vsm_ctx::ResultSlot& R) {
+            launch_kmeans_accumulate(c->d_pairs.as<SiftPair>(), m, R.d_offsets.as<int64_t>(), R.d_tight1.as<int32_t>(), K,
+                                     d_sums, d_cnt, c->stream);
+        });
+        if (rc != VSM_OK) {
+            vsm_release_set(c, vocab);
+            return rc;
+        }
+        launch_kmeans_update(d_sums, d_cnt, K, d_words, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        vsm_release_set(c, vocab);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(words, d_words, (size_t)K * kDescDim, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return K;
 }
