@@ -148,7 +148,7 @@ def test_sharded_verification_equals_the_unsharded_run(tmp_path):
     assert os.path.getsize(whole_in) > 5000
 
 
-@pytest.mark.parametrize("own_words", [True, False])
+@pytest.mark.parametrize("own_words", [True, False, "kmeans"])
 def test_cli_pairs_from_a_vocabulary(tmp_path, own_words):
     """--pairs vocab: the pair list is the shortlist the oracle computes from the same words (drawn from
     the images by the driver's rule, or read from a .sift file), and every listed pair is matched."""
@@ -159,7 +159,10 @@ def test_cli_pairs_from_a_vocabulary(tmp_path, own_words):
     num, topk, nwords = len(images), 2, 700
     out = str(tmp_path / "matching.txt")
     cmd = [CLI, "--sift-dir", str(tmp_path), "--num", str(num), "--out", out, "--pairs", "vocab", "--topk", str(topk)]
-    if own_words:
+    if own_words == "kmeans":
+        cmd += ["--vocab-size", str(nwords), "--kmeans", "3"]
+        vocab = orc.train_vocabulary(images, nwords, 3)
+    elif own_words:
         cmd += ["--vocab-size", str(nwords)]
         words = []
         for i, des in enumerate(images):
@@ -174,6 +177,7 @@ def test_cli_pairs_from_a_vocabulary(tmp_path, own_words):
     assert res.returncode == 0, res.stderr
     pairs, _ = orc.shortlist([orc.knn2_u8(img, vocab)[0] for img in images], len(vocab), topk)
     assert (group[pairs[:, 0]] == group[pairs[:, 1]]).sum() == 4 * 3
+    assert ("%d pairs" % len(pairs)) in res.stderr
     expect = []
     for a, b in pairs:
         m0, _ = orc.match_dense_u8(images[a], images[b], orc.params((4, 5), True))

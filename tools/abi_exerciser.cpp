@@ -129,6 +129,8 @@ int main()
         std::vector<int32_t> sp(2 * 6), sc(16);
         CHECK(vsm_shortlist_pairs(ctx, imgs, 4, vs, 2, sp.data(), 6, sc.data()));
         CHECK(vsm_shortlist_pairs(ctx, imgs, 4, vs, 1, sp.data(), 6, nullptr));
+        std::vector<uint8_t> trained(50 * 128);
+        CHECK(vsm_train_vocabulary(ctx, imgs, 4, 50, 2, trained.data()));
     }
     printf("kernel ms %.3f, verify ms %.3f, last pairs %d\n", vsm_last_kernel_ms(ctx), vsm_last_verify_ms(ctx), vsm_last_submission_pairs(ctx));
     vsm_destroy(ctx);

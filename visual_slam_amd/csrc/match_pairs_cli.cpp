@@ -26,7 +26,7 @@ struct Options {
     int shard = 0, nshards = 1;
     bool exhaustive = true, mutual = true, write_mat = false, append = false;
     bool by_vocab = false;        // pair list from a visual vocabulary (vsm_shortlist_pairs)
-    int vocab_size = 4096, topk = 20;
+    int vocab_size = 4096, topk = 20, kmeans = 0;
     std::string vocab_file;       // .sift file whose descriptors are the words; empty: rows drawn from the images
     int consecutive = 3;
     std::vector<int32_t> discrete{7, 15};
@@ -50,6 +50,8 @@ void usage()
             "  --topk T              vocab list: partners chosen per image (default 20)\n"
             "  --vocab FILE.sift     vocab list: the words; without it --vocab-size K (default 4096) rows are\n"
             "                        taken from the images themselves, evenly spread\n"
+            "  --kmeans N            vocab list without --vocab: the words are the result of N k-means iterations\n"
+            "                        over all descriptors (default 0: the drawn rows as they are)\n"
             "  --consecutive K       window list: pairs (i, i+1..i+K)          (default 3)\n"
             "  --discrete A,B,...    window list: pairs (i, i+A), (i, i+B) ... (default 7,15)\n"
             "  --ratio NUM/DEN       Lowe ratio, exact rational (default 4/5; 0/1 disables)\n"
@@ -90,6 +92,7 @@ bool parse(int argc, char** argv, Options& o)
         }
         else if (a == "--topk") { if (!(v = next("--topk"))) return false; o.topk = atoi(v); }
         else if (a == "--vocab") { if (!(v = next("--vocab"))) return false; o.vocab_file = v; }
+        else if (a == "--kmeans") { if (!(v = next("--kmeans"))) return false; o.kmeans = atoi(v); }
         else if (a == "--vocab-size") { if (!(v = next("--vocab-size"))) return false; o.vocab_size = atoi(v); }
         else if (a == "--consecutive") { if (!(v = next("--consecutive"))) return false; o.consecutive = atoi(v); }
         else if (a == "--discrete") {
@@ -152,7 +155,7 @@ int main(int argc, char** argv)
     std::vector<int> set_id(o.num, -1), count(o.num, 0), xy_id(o.num, -1);
     const bool verify = o.verify > 0.0f;
     // words drawn from the images: vocab_size / num rows of each (one more from the first vocab_size % num), evenly spread
-    const bool draw_words = o.by_vocab && o.vocab_file.empty();
+    const bool draw_words = o.by_vocab && o.vocab_file.empty() && o.kmeans <= 0;
     std::vector<uint8_t> words;
     {
         const int kChunk = 256;
@@ -220,7 +223,15 @@ int main(int argc, char** argv)
     std::vector<int32_t> pairs;
     long long npairs;
     if (o.by_vocab) {
-        if (!draw_words) {
+        if (o.vocab_file.empty() && o.kmeans > 0) {
+            words.resize((size_t)o.vocab_size * VSM_DESC_DIM_U8);
+            const int k = vsm_train_vocabulary(ctx, set_id.data(), o.num, o.vocab_size, o.kmeans, words.data());
+            if (k < 0) {
+                fprintf(stderr, "vsm_train_vocabulary: %s\n", vsm_last_error(ctx));
+                return 1;
+            }
+            words.resize((size_t)k * VSM_DESC_DIM_U8);
+        } else if (!draw_words) {
             int n = 0;
             if (!vsm_sift_read(o.vocab_file.c_str(), nullptr, nullptr, 0, &n, nullptr) || n <= 0) {
                 fprintf(stderr, "cannot read the vocabulary %s\n", o.vocab_file.c_str());

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void kmeans_seed_kernel(const int8_t* const* _
 __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const SiftPair* __restrict__ pairs,
                                                                 const int64_t* __restrict__ offsets,
                                                                 const int32_t* __restrict__ words, int nwords,
-                                                                unsigned long long* __restrict__ sums,
+                                                                unsigned* __restrict__ sums,
                                                                 unsigned* __restrict__ counts)
 {
     const int p = blockIdx.y, lane = threadIdx.x & 63;
@@ -278,21 +278,21 @@ __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const SiftPair* 
     for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += gridDim.x * 4) {
         const int w = words[off + r];
         if (w < 0 || w >= nwords) continue;
-        atomicAdd(&sums[(size_t)w * kDescDim + lane], (unsigned long long)frag_byte(frag, r, lane));
-        atomicAdd(&sums[(size_t)w * kDescDim + 64 + lane], (unsigned long long)frag_byte(frag, r, 64 + lane));
+        atomicAdd(&sums[(size_t)w * kDescDim + lane], frag_byte(frag, r, lane));
+        atomicAdd(&sums[(size_t)w * kDescDim + 64 + lane], frag_byte(frag, r, 64 + lane));
         if (lane == 0) atomicAdd(&counts[w], 1u);
     }
 }
 
 // word = round-half-up of the mean of its rows; a word without rows keeps its value.
-__global__ __launch_bounds__(256) void kmeans_update_kernel(const unsigned long long* __restrict__ sums,
+__global__ __launch_bounds__(256) void kmeans_update_kernel(const unsigned* __restrict__ sums,
                                                             const unsigned* __restrict__ counts, int nwords,
                                                             uint8_t* __restrict__ words)
 {
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= (size_t)nwords * kDescDim) return;
     const unsigned long long c = counts[k / kDescDim];
-    if (c) words[k] = (uint8_t)((2ull * sums[k] + c) / (2ull * c));
+    if (c) words[k] = (uint8_t)((2ull * sums[k] + c) / (2ull * c));   // sums < 2^32: at most 2^24 rows of bytes
 }
 
 }  // namespace
@@ -304,14 +304,14 @@ void launch_kmeans_seed(const int8_t* const* frags, const int32_t* rows, int nwo
 }
 
 void launch_kmeans_accumulate(const SiftPair* pairs, int nimages, const int64_t* offsets, const int32_t* words,
-                              int nwords, unsigned long long* sums, unsigned* counts, hipStream_t s)
+                              int nwords, unsigned* sums, unsigned* counts, hipStream_t s)
 {
     if (nimages <= 0) return;
     hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3(64, nimages), dim3(256), 0, s, pairs, offsets, words, nwords,
                        sums, counts);
 }
 
-void launch_kmeans_update(const unsigned long long* sums, const unsigned* counts, int nwords, uint8_t* words,
+void launch_kmeans_update(const unsigned* sums, const unsigned* counts, int nwords, uint8_t* words,
                           hipStream_t s)
 {
     if (nwords <= 0) return;

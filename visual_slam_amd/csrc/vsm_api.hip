@@ -1778,6 +1778,7 @@ extern "C" int vsm_train_vocabulary(vsm_ctx* c, const int32_t* sets, int nimg, i
         total += A->n;
     }
     if (total == 0) return 0;
+    if (total > (1 << 24)) return fail(c, VSM_EINVAL, "%lld descriptor rows (limit %d: sums of bytes are kept in 32 bits)", (long long)total, 1 << 24);
     const int K = (int)std::min<int64_t>(nwords, total);
     HIPCHK(c, hipSetDevice(c->device));
     // first values: rows floor(k * total / K) of the concatenation of the sets, k = 0 .. K-1
@@ -1794,12 +1795,12 @@ extern "C" int vsm_train_vocabulary(vsm_ctx* c, const int32_t* sets, int nimg, i
         }
     }
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t b_words = up((size_t)K * kDescDim), b_sums = up((size_t)K * kDescDim * 8), b_cnt = up((size_t)K * 4);
+    const size_t b_words = up((size_t)K * kDescDim), b_sums = up((size_t)K * kDescDim * 4), b_cnt = up((size_t)K * 4);
     const size_t b_frags = up((size_t)K * sizeof(void*)), b_rows = up((size_t)K * 4);
     HIPCHK(c, c->d_short.ensure(b_words + b_sums + b_cnt + b_frags + b_rows));
     char* w = c->d_short.as<char>();
     uint8_t* d_words = reinterpret_cast<uint8_t*>(w); w += b_words;
-    unsigned long long* d_sums = reinterpret_cast<unsigned long long*>(w); w += b_sums;
+    unsigned* d_sums = reinterpret_cast<unsigned*>(w); w += b_sums;
     unsigned* d_cnt = reinterpret_cast<unsigned*>(w); w += b_cnt;
     const int8_t** d_frags = reinterpret_cast<const int8_t**>(w); w += b_frags;
     int32_t* d_rows = reinterpret_cast<int32_t*>(w); w += b_rows;

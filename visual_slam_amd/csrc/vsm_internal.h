@@ -212,11 +212,12 @@ void launch_bow_shortlist(uint32_t* hist, int nimg, int nwords, int topk, uint32
 
 // vocabulary training on u8 sets: first values (word w = row rows[w] of the set whose fragment-major
 // data is frags[w]), sums of the rows of every word over a submission of (image, vocabulary) pairs with
-// every row accepted (sums [nwords][128], counts [nwords], zeroed by the caller), rounded means.
+// every row accepted (sums [nwords][128], counts [nwords], zeroed by the caller; 32-bit sums: at most 2^24
+// rows in all), rounded means.
 void launch_kmeans_seed(const int8_t* const* frags, const int32_t* rows, int nwords, uint8_t* words, hipStream_t s);
 void launch_kmeans_accumulate(const SiftPair* pairs, int nimages, const int64_t* offsets, const int32_t* words,
-                              int nwords, unsigned long long* sums, unsigned* counts, hipStream_t s);
-void launch_kmeans_update(const unsigned long long* sums, const unsigned* counts, int nwords, uint8_t* words,
+                              int nwords, unsigned* sums, unsigned* counts, hipStream_t s);
+void launch_kmeans_update(const unsigned* sums, const unsigned* counts, int nwords, uint8_t* words,
                           hipStream_t s);
 
 void launch_pack(const SiftPair* pairs, int npairs, const int32_t* counts, int64_t* offsets,
