@@ -28,11 +28,11 @@ F32_MFMA_PEAK_TFLOPS = 157.3    # f32-input MFMA (exact f32), = vector peak
 BF16_DENSE_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA
 
 
-def measured_traffic(kernel):
+def measured_traffic(kernel, summary="r01_traffic_sift_exhaustive.json"):
     """HBM bytes per launch of `kernel` from the committed hardware-counter passes (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE over tools/traffic_probe.py at this workload's shape, folded by
-    tools/pmc_summary.py); None when no such pass is in the tree."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic_sift_exhaustive.json")
+    FETCH_SIZE / WRITE_SIZE over tools/traffic_probe.py or tools/db_query_probe.py at this workload's
+    shape, folded by tools/pmc_summary.py); None when no such pass is in the tree."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", summary)
     try:
         with open(path) as f:
             return float(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
@@ -616,6 +616,8 @@ def run_db_query(args, torch, dist, world, rank):
                    "parallelism": "database sliced x%d, RCCL all-gather of the per-slice 2-NN lists, device merge" % world},
         "roofline": f32_roofline(m, OPS_PER_EVAL_F32 * float(nq) * (hi - lo), kms),
     }
+    if world == 1 and m.last_f32_path() == 0:   # the counter passes were taken at this shape
+        out["roofline"]["traffic"] = measured_traffic("void vsm::bf16_coarse_kernel<256>", "r01_traffic_db_query.json")
     m.close()
     return out
 

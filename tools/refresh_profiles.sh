@@ -32,6 +32,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "pmc $c done"
 done
 python3 $root/tools/pmc_summary.py $out/${tag}_probe1000_pmc_FETCH_SIZE.csv $out/${tag}_probe1000_pmc_WRITE_SIZE.csv $out/${tag}_traffic_sift_exhaustive.json
+# the same two passes over the float database query (16384 x 1 M x 256)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_db_$c
+  timeout -s KILL 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_db_$c -- python3 $root/tools/db_query_probe.py > /tmp/pmc_db_$c.log 2>&1
+  cp "$(find /tmp/pmc_db_$c -name '*counter_collection.csv' | head -1)" $out/${tag}_dbquery_pmc_$c.csv
+done
+python3 $root/tools/pmc_summary.py $out/${tag}_dbquery_pmc_FETCH_SIZE.csv $out/${tag}_dbquery_pmc_WRITE_SIZE.csv $out/${tag}_traffic_db_query.json
 # matrix-core utilisation of the SIFT kernels: busy cycles of the matrix pipes against elapsed cycles x SIMDs
 rm -rf /tmp/pmc_mfma
 timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INSTS_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_mfma -- python3 $root/tools/traffic_probe.py --images 300 > /tmp/pmc_mfma.log 2>&1
