@@ -173,3 +173,41 @@ def test_large_sets_random(matcher, seed):
     finally:
         matcher.release(s0)
         matcher.release(s1)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_shortlist_and_vocabulary_random(matcher, seed):
+    """Random collections (sizes from 0, near-copies, shared rows), random vocabulary sizes, top-k and
+    iteration counts: trained words, score matrix and pair list against the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    nimg = int(rng.integers(1, 40))
+    pool = synth.sift_like(64, rng)
+    images = []
+    for _ in range(nimg):
+        n = int(rng.choice([0, 1, 31, 200, 513, 900])) if rng.random() < 0.5 else int(rng.integers(0, 400))
+        img = synth.sift_like(n, rng)
+        k = int(n * rng.random() * 0.7)
+        if k:
+            img[:k] = np.clip(pool[rng.integers(0, 64, k)].astype(np.int32) + rng.integers(-3, 4, (k, 128)), 0, 255)
+        images.append(img)
+    if nimg > 2 and rng.random() < 0.5:
+        images[2] = images[0].copy()
+    nwords = int(rng.choice([1, 2, 33, 64, 300, 1000]))
+    iterations = int(rng.integers(0, 4))
+    topk = int(rng.choice([1, 2, 5, 50]))
+    ids = [matcher.upload_u8(img) for img in images]
+    vid = None
+    try:
+        words = matcher.train_vocabulary(ids, nwords, iterations)
+        ewords = orc.train_vocabulary(images, nwords, iterations) if sum(map(len, images)) else np.zeros((0, 128), np.uint8)
+        np.testing.assert_array_equal(words, ewords)
+        if len(words):
+            vid = matcher.upload_u8(words)
+            pairs, scores = matcher.shortlist_pairs(ids, vid, topk, want_scores=True)
+            wl = [orc.knn2_u8(img, words)[0] if len(img) else np.zeros(0, np.int32) for img in images]
+            epairs, escores = orc.shortlist(wl, len(words), topk)
+            np.testing.assert_array_equal(scores, escores)
+            np.testing.assert_array_equal(pairs, epairs)
+    finally:
+        for s in ids + ([vid] if vid is not None else []):
+            matcher.release(s)
