@@ -508,7 +508,7 @@ def run_shortlist(args, torch, dist, world, rank):
     """Pair shortlist for the exhaustive workload's collection: 1000 images x 8192 SIFT features, a
     vocabulary of 4096 words drawn from them, 20 partners per image.  One step = one whole shortlist
     (word assignment of 8.2 M descriptors, histograms, 1000 x 1000 scores, choices).  Does not shard:
-    with more than one rank every rank computes the same list (replicas only)."""
+    with more than one rank every rank computes the same list and the value counts all of them (replicas only)."""
     import visual_slam_amd as vsm
 
     nimg, nfeat, nwords, topk = args.images, args.features, 4096, 20
@@ -536,7 +536,7 @@ def run_shortlist(args, torch, dist, world, rank):
     ops = OPS_PER_EVAL_U8 * float(nimg) * nfeat * nwords    # the word assignment; the rest is < 1 % of the work
     achieved = ops / (kms * 1e-3) / 1e12
     out = {
-        "metric": "images shortlisted/sec", "value": args.steps * nimg / dt, "unit": "images/s",
+        "metric": "images shortlisted/sec", "value": world * args.steps * nimg / dt, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "replicas",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
