@@ -127,3 +127,27 @@ def test_train_vocabulary_rejects_float_sets(matcher):
     with pytest.raises(vsm.VsmError):
         matcher.train_vocabulary([f], 4, 1)
     assert len(matcher.train_vocabulary([], 4, 1)) == 0
+
+
+def test_small_scratch_budget_cuts_the_assignment_into_groups(matcher):
+    rng = np.random.default_rng(12)
+    images = [synth.sift_like(int(rng.integers(500, 900)), rng) for _ in range(40)]
+    for k in range(1, 40, 4):
+        images[k][:300] = images[k - 1][:300]
+    matcher.set_scratch_budget(1 << 20)       # about 6500 descriptor rows per submission
+    try:
+        ids = [matcher.upload_u8(img) for img in images]
+        words = matcher.train_vocabulary(ids, 64, 2)
+        for s in ids:
+            matcher.release(s)
+        np.testing.assert_array_equal(words, orc.train_vocabulary(images, 64, 2))
+        _check(matcher, images, words, 3)
+        tiny = [synth.sift_like(4, rng) for _ in range(300)]
+        ids = [matcher.upload_u8(img) for img in tiny]
+        big = matcher.upload_u8(synth.sift_like(1000, rng))
+        with pytest.raises(vsm.VsmError):
+            matcher.shortlist_pairs(ids, big, 2)     # 300 x 1000 counters alone pass the budget
+        for s in ids + [big]:
+            matcher.release(s)
+    finally:
+        matcher.set_scratch_budget(8 << 30)
