@@ -210,6 +210,15 @@ int vsm_sift_write(const char* path, const float* loc, int nloc_dim,
 /* save_feature_locations (main.py:133-140) / ReadLocFromText (FeaturePoints.cpp:326-369). */
 int vsm_feature_txt_write(const char* path, const float* xy, int m);
 int vsm_feature_txt_read(const char* path, float* xy, int cap);
+/* The two conversions of the reference's converter program (test_main.cpp:30-60).
+ * vsm_sift_to_txt: FeatureData::ReadSIFTB + Sift2Txt (FeaturePoints.cpp:306-325) for VSM_TXT_BOTH: one
+ * row per feature, the location values (as `ofstream << float` prints them) then the 128 descriptor
+ * bytes, every value followed by a blank; write_out_data (:281-305) for VSM_TXT_LOCATIONS /
+ * VSM_TXT_DESCRIPTORS.  vsm_txt_to_sift: ReadLocFromText (:326-369) + saveSIFTB2 (:228-280): locations
+ * (x, y, 0, 0, 0), descriptors of all ones.  Both return the feature count or a negative code. */
+enum { VSM_TXT_BOTH = 0, VSM_TXT_LOCATIONS = 1, VSM_TXT_DESCRIPTORS = 2 };
+int vsm_sift_to_txt(const char* sift_path, const char* txt_path, int what);
+int vsm_txt_to_sift(const char* txt_path, const char* sift_path);
 /* get_list_matching_pairs + save_matching_sfm (main.py:114-155): appends one record
  * built from the dense matches0[n] (-1 = none).  Returns the match count. */
 int vsm_matchtxt_append_dense(const char* path, const char* name0, const char* name1,

@@ -89,6 +89,8 @@ SIGNATURES = {
     "vsm_matchtxt_write": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "vsm_matchtxt_close": (C.c_int, [C.c_void_p]),
     "vsm_image_pairs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "vsm_sift_to_txt": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
+    "vsm_txt_to_sift": (C.c_int, [C.c_char_p, C.c_char_p]),
     "vsm_image_pairs_exhaustive": (C.c_longlong, [C.c_int, C.c_void_p, C.c_longlong]),
     "vsm_train_vocabulary": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vsm_shortlist_pairs": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong,

@@ -207,6 +207,56 @@ extern "C" int vsm_feature_txt_read(const char* path, float* xy, int cap)
     return m;
 }
 
+// FeatureData::Sift2Txt (FeaturePoints.cpp:306-325) and write_out_data (:281-305): the features of a
+// .sift file as text, one row per feature, every value followed by a blank.  Locations are written
+// the way `ofstream << float` writes them (six significant digits, %g), descriptor bytes as integers.
+extern "C" int vsm_sift_to_txt(const char* sift_path, const char* txt_path, int what)
+{
+    if (!sift_path || !txt_path || what < VSM_TXT_BOTH || what > VSM_TXT_DESCRIPTORS) return VSM_EINVAL;
+    int n = 0, nloc = 0;
+    if (!vsm_sift_read(sift_path, nullptr, nullptr, 0, &n, &nloc)) return VSM_EFORMAT;
+    std::vector<float> loc((size_t)n * nloc + 1);
+    std::vector<uint8_t> des((size_t)n * VSM_DESC_DIM_U8 + 1);
+    if (n > 0 && !vsm_sift_read(sift_path, loc.data(), des.data(), n, nullptr, nullptr)) return VSM_EFORMAT;
+    std::string out;
+    out.reserve((size_t)n * (what == VSM_TXT_LOCATIONS ? 64 : 600));
+    char num[48];
+    for (int i = 0; i < n; ++i) {
+        if (what != VSM_TXT_DESCRIPTORS)
+            for (int j = 0; j < nloc; ++j) {
+                const int len = snprintf(num, sizeof num, "%g ", (double)loc[(size_t)i * nloc + j]);
+                out.append(num, len);
+            }
+        if (what != VSM_TXT_LOCATIONS)
+            for (int j = 0; j < VSM_DESC_DIM_U8; ++j) {
+                char* p = put_int(num, des[(size_t)i * VSM_DESC_DIM_U8 + j]);
+                *p++ = ' ';
+                out.append(num, p - num);
+            }
+        out.push_back('\n');
+    }
+    Fd f(::open(txt_path, O_CREAT | O_WRONLY | O_TRUNC, 0644));
+    if (!f.ok() || !f.write_all(out.data(), out.size())) return VSM_EIO;
+    return n;
+}
+
+// txt2sift of test_main.cpp:46-60: ReadLocFromText (FeaturePoints.cpp:326-369: locations x, y, 0, 0, 0
+// and descriptors of all ones) followed by saveSIFTB2.
+extern "C" int vsm_txt_to_sift(const char* txt_path, const char* sift_path)
+{
+    if (!txt_path || !sift_path) return VSM_EINVAL;
+    const int m = vsm_feature_txt_read(txt_path, nullptr, 0);
+    if (m < 0) return m;
+    std::vector<float> xy((size_t)m * 2 + 1), loc((size_t)m * 5 + 1, 0.0f);
+    if (m > 0 && vsm_feature_txt_read(txt_path, xy.data(), m) != m) return VSM_EFORMAT;
+    for (int i = 0; i < m; ++i) {
+        loc[(size_t)i * 5] = xy[2 * i];
+        loc[(size_t)i * 5 + 1] = xy[2 * i + 1];
+    }
+    const std::vector<uint8_t> des((size_t)m * VSM_DESC_DIM_U8 + 1, 1);
+    return vsm_sift_write(sift_path, loc.data(), 5, des.data(), m) ? m : VSM_EIO;
+}
+
 // =====================================================================================
 // match txt
 // =====================================================================================

@@ -90,6 +90,24 @@ def read_feature_locations(path):
     return xy[:n]
 
 
+# ---- the converter program (test_main.cpp:30-60) ------------------------------------------------------
+def sift2txt(sift_path, txt_path, what="both"):
+    """FeatureData::ReadSIFTB + Sift2Txt (or write_out_data for "locations" / "descriptors")."""
+    code = {"both": 0, "locations": 1, "descriptors": 2}[what]
+    n = B.lib().vsm_sift_to_txt(_b(sift_path), _b(txt_path), code)
+    if n < 0:
+        raise B.VsmError(n, "vsm_sift_to_txt(%s)" % sift_path)
+    return n
+
+
+def txt2sift(txt_path, sift_path):
+    """FeatureData::ReadLocFromText + saveSIFTB2: keypoint txt -> .sift with placeholder descriptors."""
+    n = B.lib().vsm_txt_to_sift(_b(txt_path), _b(sift_path))
+    if n < 0:
+        raise B.VsmError(n, "vsm_txt_to_sift(%s)" % txt_path)
+    return n
+
+
 # ---- .sift (FeaturePoints.cpp:228-280, 388-446) ---------------------------------------------------
 def read_sift(path, nmax=None):
     """Returns (loc float32 [n, nloc_dim], des uint8 [n, 128]) or raises."""
