@@ -77,6 +77,17 @@ int main(int argc, char** argv)
     vsm_feature_txt_write((dir + "/k.txt").c_str(), xy, 3);
     vsm_feature_txt_read((dir + "/k.txt").c_str(), back, 3);
     vsm_feature_txt_read((dir + "/k.txt").c_str(), back, 1);
+    // the converter's two directions, and a keypoint txt that announces more rows than it holds
+    if (vsm_txt_to_sift((dir + "/k.txt").c_str(), (dir + "/k.sift").c_str()) != 3) return 1;
+    for (int what = 0; what < 3; ++what)
+        if (vsm_sift_to_txt((dir + "/k.sift").c_str(), (dir + "/k_back.txt").c_str(), what) != 3) return 1;
+    {
+        FILE* fp = fopen((dir + "/short.txt").c_str(), "w");
+        fputs("5 0\n1 2\n", fp);
+        fclose(fp);
+        if (vsm_txt_to_sift((dir + "/short.txt").c_str(), (dir + "/short.sift").c_str()) >= 0) return 1;
+        if (vsm_sift_to_txt((dir + "/short.txt").c_str(), (dir + "/o.txt").c_str(), 0) >= 0) return 1;
+    }
     int32_t disc[2] = {7, 15};
     std::vector<int32_t> pairs(2 * 5000);
     vsm_image_pairs(1000, 3, disc, 2, pairs.data(), 5000);
