@@ -57,19 +57,21 @@ def test_cli_matches_oracle(tmp_path, mode):
     assert sum(len(e.splitlines()[1].split()) for e in expect) > 100
 
 
-def test_sharded_runs_concatenate_to_the_unsharded_file(tmp_path):
-    """Two processes on contiguous slices of the pair list (here both on GPU 0) = one process on all of it."""
+@pytest.mark.parametrize("pair_args", [[], ["--pairs", "vocab", "--topk", "2", "--vocab-size", "300", "--kmeans", "2"]])
+def test_sharded_runs_concatenate_to_the_unsharded_file(tmp_path, pair_args):
+    """Three processes on contiguous slices of the pair list (here all on GPU 0) = one process on all of it;
+    with a vocabulary pair list every process derives the same list before it takes its slice."""
     import sys
     sizes = [400, 300, 513, 256, 700, 120, 333]
     _make_images(tmp_path, sizes, seed=22)
     whole = str(tmp_path / "whole.txt")
-    res = subprocess.run([CLI, "--sift-dir", str(tmp_path), "--num", str(len(sizes)), "--out", whole, "--batch", "5"],
+    res = subprocess.run([CLI, "--sift-dir", str(tmp_path), "--num", str(len(sizes)), "--out", whole, "--batch", "5"] + pair_args,
                          capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
     sharded = str(tmp_path / "sharded.txt")
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "match_multi_gpu.py")
     res = subprocess.run([sys.executable, tool, "--sift-dir", str(tmp_path), "--num", str(len(sizes)), "--out", sharded,
-                          "--devices", "0,0,0", "--batch", "4"], capture_output=True, text=True, timeout=180)
+                          "--devices", "0,0,0", "--batch", "4"] + pair_args, capture_output=True, text=True, timeout=180)
     assert res.returncode == 0, res.stderr
     assert open(sharded, "rb").read() == open(whole, "rb").read()
     assert os.path.getsize(whole) > 1000
