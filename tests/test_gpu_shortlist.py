@@ -151,3 +151,13 @@ def test_small_scratch_budget_cuts_the_assignment_into_groups(matcher):
             matcher.release(s)
     finally:
         matcher.set_scratch_budget(8 << 30)
+
+
+def test_float_descriptors_on_the_f32_only_path(matcher):
+    images, _ = synth.image_groups(3, 3, 200, seed=41, shared=0.5, noise=0.01, dtype="f32", dim=128)
+    vocab = synth.sample_vocabulary(images, 150, seed=42)
+    matcher.set_f32_mode(vsm.F32_MFMA_F32)
+    try:
+        _check(matcher, images, vocab, 2)
+    finally:
+        matcher.set_f32_mode(vsm.F32_FAST_EXACT)
