@@ -64,7 +64,8 @@ void usage()
             "  --inlier-out FILE     match txt of the verified matches (same format as --out)\n"
             "  --name-ext EXT        image-name suffix in the match txt (default .jpg)\n"
             "  --device N, --batch P (pairs per GPU submission, default 4096; two are in flight)\n"
-            "  --shard R/W           match only the R-th of W contiguous slices of the pair list (one process\n"
+            "  --shard R/W           match only the R-th of W contiguous slices of the pair list, cut at equal\n"
+            "                        shares of the work (rows x rows per pair) (one process\n"
             "                        per GPU); with W > 1 the text goes to FILE.partR: concatenating the parts in\n"
             "                        order gives the file of an unsharded run\n");
 }
@@ -271,8 +272,18 @@ int main(int argc, char** argv)
     // this process's slice of the pair list
     long long first_of_shard = 0;
     if (o.nshards > 1) {
-        const long long per = (npairs + o.nshards - 1) / o.nshards;
-        const long long lo = std::min<long long>(npairs, per * o.shard), hi = std::min<long long>(npairs, lo + per);
+        // contiguous slices of about equal work (rows of image 0 x rows of image 1 per pair), so that the
+        // parts still concatenate in pair order; every process finds the same cuts
+        std::vector<double> upto((size_t)npairs + 1, 0.0);
+        for (long long k = 0; k < npairs; ++k)
+            upto[k + 1] = upto[k] + ((double)count[pairs[2 * k]] + 1.0) * ((double)count[pairs[2 * k + 1]] + 1.0);
+        auto cut = [&](int r) {
+            if (r <= 0) return 0ll;
+            if (r >= o.nshards) return npairs;
+            const double want = upto[npairs] * r / o.nshards;
+            return (long long)(std::lower_bound(upto.begin(), upto.end(), want) - upto.begin());
+        };
+        const long long lo = cut(o.shard), hi = std::max(lo, cut(o.shard + 1));
         first_of_shard = lo;
         pairs.erase(pairs.begin(), pairs.begin() + 2 * lo);
         pairs.resize((size_t)(hi - lo) * 2 + 2);
