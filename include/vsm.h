@@ -258,6 +258,10 @@ long long vsm_shortlist_pairs(vsm_ctx* ctx, const int32_t* sets, int nimg, int v
  * a word without rows keeps its value.  words receives K rows of 128 bytes.  Returns K. */
 int vsm_train_vocabulary(vsm_ctx* ctx, const int32_t* sets, int nimg, int nwords, int iterations,
                          uint8_t* words);
+/* A new resident u8 set holding rows 0, stride, 2 * stride, ... of the concatenation of the sets: a
+ * subsample to train a vocabulary on (vsm_train_vocabulary over that one set).  Returns the set id;
+ * release it with vsm_release_set. */
+int vsm_sample_rows_u8(vsm_ctx* ctx, const int32_t* sets, int nimg, int stride);
 /* MatchFile::WritePMatch(image1, image2, fc1, fc2, NM, matches) (MatchFile.cpp:751-832):
  * image paths without extension; writes <image1>.mat and <image2>.mat.
  * reservation = MatchFile::SetRecordReservation (MatchFile.h:244); pass 0 for the

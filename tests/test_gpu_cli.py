@@ -150,7 +150,7 @@ def test_sharded_verification_equals_the_unsharded_run(tmp_path):
     assert os.path.getsize(whole_in) > 5000
 
 
-@pytest.mark.parametrize("own_words", [True, False, "kmeans"])
+@pytest.mark.parametrize("own_words", [True, False, "kmeans", "kmeans-sampled"])
 def test_cli_pairs_from_a_vocabulary(tmp_path, own_words):
     """--pairs vocab: the pair list is the shortlist the oracle computes from the same words (drawn from
     the images by the driver's rule, or read from a .sift file), and every listed pair is matched."""
@@ -161,7 +161,10 @@ def test_cli_pairs_from_a_vocabulary(tmp_path, own_words):
     num, topk, nwords = len(images), 2, 700
     out = str(tmp_path / "matching.txt")
     cmd = [CLI, "--sift-dir", str(tmp_path), "--num", str(num), "--out", out, "--pairs", "vocab", "--topk", str(topk)]
-    if own_words == "kmeans":
+    if own_words == "kmeans-sampled":
+        cmd += ["--vocab-size", str(nwords), "--kmeans", "2", "--kmeans-stride", "3"]
+        vocab = orc.train_vocabulary([np.concatenate(images)[::3]], nwords, 2)
+    elif own_words == "kmeans":
         cmd += ["--vocab-size", str(nwords), "--kmeans", "3"]
         vocab = orc.train_vocabulary(images, nwords, 3)
     elif own_words:

@@ -161,3 +161,18 @@ def test_float_descriptors_on_the_f32_only_path(matcher):
         _check(matcher, images, vocab, 2)
     finally:
         matcher.set_f32_mode(vsm.F32_FAST_EXACT)
+
+
+@pytest.mark.parametrize("sizes,stride", [([300, 0, 200, 513], 7), ([40], 1), ([5, 3, 9], 100), ([700] * 4, 64)])
+def test_sampled_rows_are_every_nth_row_of_the_concatenation(matcher, sizes, stride):
+    rng = np.random.default_rng(stride + len(sizes))
+    images = [synth.sift_like(n, rng) for n in sizes]
+    ids = [matcher.upload_u8(img) for img in images]
+    sample = matcher.sample_rows(ids, stride)
+    expect = np.concatenate(images)[::stride]
+    assert matcher.count(sample) == len(expect)
+    # a vocabulary of as many words as rows, no iterations: the rows themselves
+    np.testing.assert_array_equal(matcher.train_vocabulary([sample], len(expect), 0), expect)
+    np.testing.assert_array_equal(matcher.train_vocabulary([sample], 16, 3), orc.train_vocabulary([expect], 16, 3))
+    for s in ids + [sample]:
+        matcher.release(s)

@@ -131,6 +131,10 @@ int main()
         CHECK(vsm_shortlist_pairs(ctx, imgs, 4, vs, 1, sp.data(), 6, nullptr));
         std::vector<uint8_t> trained(50 * 128);
         CHECK(vsm_train_vocabulary(ctx, imgs, 4, 50, 2, trained.data()));
+        const int sampled = vsm_sample_rows_u8(ctx, imgs, 4, 9);
+        CHECK(sampled);
+        CHECK(vsm_train_vocabulary(ctx, &sampled, 1, 20, 1, trained.data()));
+        vsm_release_set(ctx, sampled);
     }
     printf("kernel ms %.3f, verify ms %.3f, last pairs %d\n", vsm_last_kernel_ms(ctx), vsm_last_verify_ms(ctx), vsm_last_submission_pairs(ctx));
     vsm_destroy(ctx);

@@ -92,6 +92,7 @@ SIGNATURES = {
     "vsm_sift_to_txt": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
     "vsm_txt_to_sift": (C.c_int, [C.c_char_p, C.c_char_p]),
     "vsm_image_pairs_exhaustive": (C.c_longlong, [C.c_int, C.c_void_p, C.c_longlong]),
+    "vsm_sample_rows_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "vsm_train_vocabulary": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vsm_shortlist_pairs": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong,
                                            C.c_void_p]),
@@ -341,6 +342,13 @@ class Matcher:
         got = self._check(self._l.vsm_shortlist_pairs(self._h, _ptr(sets), n, int(vocab_set), int(topk), _ptr(pairs),
                                                       cap, _ptr(scores)))
         return (pairs[:got], scores) if want_scores else pairs[:got]
+
+    def sample_rows(self, sets, stride):
+        """A new resident u8 set with every ``stride``-th row of the concatenation of ``sets``."""
+        sets = np.ascontiguousarray(sets, dtype=np.int32).reshape(-1)
+        sid = self._check(self._l.vsm_sample_rows_u8(self._h, _ptr(sets), sets.shape[0], int(stride)))
+        self._kinds[sid] = ("u8", self.count(sid))
+        return sid
 
     def train_vocabulary(self, sets, nwords, iterations=10):
         """k-means vocabulary over all rows of the resident u8 sets: uint8 [K, 128], K = min(nwords, rows)."""

@@ -26,7 +26,7 @@ struct Options {
     int shard = 0, nshards = 1;
     bool exhaustive = true, mutual = true, write_mat = false, append = false;
     bool by_vocab = false;        // pair list from a visual vocabulary (vsm_shortlist_pairs)
-    int vocab_size = 4096, topk = 20, kmeans = 0;
+    int vocab_size = 4096, topk = 20, kmeans = 0, kmeans_stride = 1;
     std::string vocab_file;       // .sift file whose descriptors are the words; empty: rows drawn from the images
     int consecutive = 3;
     std::vector<int32_t> discrete{7, 15};
@@ -51,7 +51,8 @@ void usage()
             "  --vocab FILE.sift     vocab list: the words; without it --vocab-size K (default 4096) rows are\n"
             "                        taken from the images themselves, evenly spread\n"
             "  --kmeans N            vocab list without --vocab: the words are the result of N k-means iterations\n"
-            "                        over all descriptors (default 0: the drawn rows as they are)\n"
+            "                        over all descriptors (default 0: the drawn rows as they are);\n"
+            "                        --kmeans-stride S trains on every S-th descriptor only\n"
             "  --consecutive K       window list: pairs (i, i+1..i+K)          (default 3)\n"
             "  --discrete A,B,...    window list: pairs (i, i+A), (i, i+B) ... (default 7,15)\n"
             "  --ratio NUM/DEN       Lowe ratio, exact rational (default 4/5; 0/1 disables)\n"
@@ -93,6 +94,7 @@ bool parse(int argc, char** argv, Options& o)
         }
         else if (a == "--topk") { if (!(v = next("--topk"))) return false; o.topk = atoi(v); }
         else if (a == "--vocab") { if (!(v = next("--vocab"))) return false; o.vocab_file = v; }
+        else if (a == "--kmeans-stride") { if (!(v = next("--kmeans-stride"))) return false; o.kmeans_stride = atoi(v); }
         else if (a == "--kmeans") { if (!(v = next("--kmeans"))) return false; o.kmeans = atoi(v); }
         else if (a == "--vocab-size") { if (!(v = next("--vocab-size"))) return false; o.vocab_size = atoi(v); }
         else if (a == "--consecutive") { if (!(v = next("--consecutive"))) return false; o.consecutive = atoi(v); }
@@ -132,7 +134,7 @@ bool parse(int argc, char** argv, Options& o)
         fprintf(stderr, "--inlier-out needs --verify\n");
         return false;
     }
-    return !o.sift_dir.empty() && o.num > 0 && o.batch > 0 && o.samples > 0 && o.topk > 0 && o.vocab_size > 0;
+    return !o.sift_dir.empty() && o.num > 0 && o.batch > 0 && o.samples > 0 && o.topk > 0 && o.vocab_size > 0 && o.kmeans_stride > 0;
 }
 
 }  // namespace
@@ -226,7 +228,14 @@ int main(int argc, char** argv)
     if (o.by_vocab) {
         if (o.vocab_file.empty() && o.kmeans > 0) {
             words.resize((size_t)o.vocab_size * VSM_DESC_DIM_U8);
-            const int k = vsm_train_vocabulary(ctx, set_id.data(), o.num, o.vocab_size, o.kmeans, words.data());
+            int k;
+            if (o.kmeans_stride > 1) {
+                const int sample = vsm_sample_rows_u8(ctx, set_id.data(), o.num, o.kmeans_stride);
+                k = sample < 0 ? sample : vsm_train_vocabulary(ctx, &sample, 1, o.vocab_size, o.kmeans, words.data());
+                if (sample >= 0) vsm_release_set(ctx, sample);
+            } else {
+                k = vsm_train_vocabulary(ctx, set_id.data(), o.num, o.vocab_size, o.kmeans, words.data());
+            }
             if (k < 0) {
                 fprintf(stderr, "vsm_train_vocabulary: %s\n", vsm_last_error(ctx));
                 return 1;

@@ -1829,3 +1829,45 @@ extern "C" int vsm_train_vocabulary(vsm_ctx* c, const int32_t* sets, int nimg, i
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return K;
 }
+
+extern "C" int vsm_sample_rows_u8(vsm_ctx* c, const int32_t* sets, int nimg, int stride)
+{
+    if (!c) return VSM_EINVAL;
+    if (nimg < 0 || (nimg > 0 && !sets) || stride < 1) return fail(c, VSM_EINVAL, "bad argument");
+    int64_t total = 0;
+    for (int i = 0; i < nimg; ++i) {
+        const DescSet* A = get_set(c, sets[i]);
+        if (!A || A->kind != SET_U8) return fail(c, VSM_EINVAL, "image %d (set %d) is not a u8 descriptor set", i, sets[i]);
+        total += A->n;
+    }
+    const int64_t m64 = (total + stride - 1) / stride;
+    if (m64 > 32767ll * kVerifyBlock) return fail(c, VSM_EINVAL, "%lld sampled rows exceed the size of one set", (long long)m64);
+    const int m = (int)m64;
+    if (m == 0) return vsm_upload_u8(c, nullptr, 0);
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<const int8_t*> frags(m);
+    std::vector<int32_t> rows(m);
+    {
+        int img = 0;
+        int64_t first = 0;
+        for (int k = 0; k < m; ++k) {
+            const int64_t g = (int64_t)k * stride;
+            while (g >= first + get_set(c, sets[img])->n) first += get_set(c, sets[img++])->n;
+            frags[k] = static_cast<const int8_t*>(get_set(c, sets[img])->frag);
+            rows[k] = (int32_t)(g - first);
+        }
+    }
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_out = up((size_t)m * kDescDim), b_frags = up((size_t)m * sizeof(void*)), b_rows = up((size_t)m * 4);
+    HIPCHK(c, c->d_short.ensure(b_out + b_frags + b_rows));
+    char* w = c->d_short.as<char>();
+    uint8_t* d_out = reinterpret_cast<uint8_t*>(w); w += b_out;
+    const int8_t** d_frags = reinterpret_cast<const int8_t**>(w); w += b_frags;
+    int32_t* d_rows = reinterpret_cast<int32_t*>(w);
+    HIPCHK(c, hipMemcpyAsync(d_frags, frags.data(), (size_t)m * sizeof(void*), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_rows, rows.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+    launch_kmeans_seed(d_frags, d_rows, m, d_out, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // frags and rows are host memory of this call
+    HIPCHK(c, hipGetLastError());
+    return vsm_upload_u8_device(c, d_out, m);
+}
