@@ -176,3 +176,14 @@ def test_sampled_rows_are_every_nth_row_of_the_concatenation(matcher, sizes, str
     np.testing.assert_array_equal(matcher.train_vocabulary([sample], 16, 3), orc.train_vocabulary([expect], 16, 3))
     for s in ids + [sample]:
         matcher.release(s)
+
+
+def test_training_a_vocabulary_of_more_than_8192_words(matcher):
+    rng = np.random.default_rng(15)
+    images = [synth.sift_like(3000, rng) for _ in range(3)]
+    images[1][:2000] = images[0][:2000]
+    ids = [matcher.upload_u8(img) for img in images]
+    words = matcher.train_vocabulary(ids, 8500, 2)
+    for s in ids:
+        matcher.release(s)
+    np.testing.assert_array_equal(words, orc.train_vocabulary(images, 8500, 2))

@@ -263,9 +263,67 @@ __global__ __launch_bounds__(256) void kmeans_seed_kernel(const int8_t* const* _
     words[(size_t)w * kDescDim + 64 + lane] = (uint8_t)frag_byte(frag, r, 64 + lane);
 }
 
-// One wave per descriptor row: adds the row to the sums of its word.  Pair p of the submission is
+// Sums of the rows of every word.  Workgroup (x, y) takes the words [x * kSumWords, (x + 1) * kSumWords)
+// and the images y, y + gridDim.y, ... of the submission: it walks the word of every row of those images,
+// adds the rows of its words into sums kept in LDS (one wave per row, two components per lane), and adds
+// the finished partial sums to memory.  Pair p of the submission is (image, vocabulary) with every row
+// accepted, so words[offsets[p] + r] is the word of row r.
+constexpr int kSumWords = 128;   // 128 words x 128 components x 4 bytes = 64 KiB of LDS
+__global__ __launch_bounds__(512) void kmeans_accumulate_kernel(const SiftPair* __restrict__ pairs, int nimages,
+                                                                const int64_t* __restrict__ offsets,
+                                                                const int32_t* __restrict__ words, int nwords,
+                                                                unsigned* __restrict__ sums,
+                                                                unsigned* __restrict__ counts)
+{
+    extern __shared__ unsigned s_sum[];   // [kSumWords][128] then [kSumWords] counts
+    unsigned* s_cnt = s_sum + kSumWords * kDescDim;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w0 = blockIdx.x * kSumWords, w1 = min(nwords, w0 + kSumWords);
+    for (int k = tid; k < kSumWords * kDescDim + kSumWords; k += 512) s_sum[k] = 0u;
+    __syncthreads();
+    for (int p = blockIdx.y; p < nimages; p += gridDim.y) {
+        const int8_t* __restrict__ frag = pairs[p].fragA;
+        const int n = pairs[p].nA;
+        const int32_t* __restrict__ wp = words + offsets[p];
+        for (int r0 = wave * 64; r0 < n; r0 += 8 * 64) {
+            const int r = r0 + lane;
+            const int w = r < n ? wp[r] : -1;
+            unsigned long long mine = __ballot(w >= w0 && w < w1);
+            while (mine) {   // four rows at a time, so that their loads are in flight together
+                int src[4], wr[4];
+                unsigned lo[4], hi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    src[u] = mine ? __ffsll((long long)mine) - 1 : -1;
+                    mine &= mine - 1;   // 0 stays 0
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (src[u] >= 0) {
+                        wr[u] = __shfl(w, src[u]) - w0;
+                        lo[u] = frag_byte(frag, r0 + src[u], lane);
+                        hi[u] = frag_byte(frag, r0 + src[u], 64 + lane);
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (src[u] >= 0) {
+                        atomicAdd(&s_sum[wr[u] * kDescDim + lane], lo[u]);
+                        atomicAdd(&s_sum[wr[u] * kDescDim + 64 + lane], hi[u]);
+                        if (lane == 0) atomicAdd(&s_cnt[wr[u]], 1u);
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < (w1 - w0) * kDescDim; k += 512)
+        if (s_sum[k]) atomicAdd(&sums[(size_t)w0 * kDescDim + k], s_sum[k]);
+    for (int k = tid; k < w1 - w0; k += 512)
+        if (s_cnt[k]) atomicAdd(&counts[w0 + k], s_cnt[k]);
+}
+
+// The same for large vocabularies, straight into memory: one wave per descriptor row adds the row to the sums of its word.  Pair p of the submission is
 // (image, vocabulary) with every row accepted, so words[offsets[p] + r] is the word of row r.
-__global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const SiftPair* __restrict__ pairs,
+__global__ __launch_bounds__(256) void kmeans_accumulate_rows_kernel(const SiftPair* __restrict__ pairs,
                                                                 const int64_t* __restrict__ offsets,
                                                                 const int32_t* __restrict__ words, int nwords,
                                                                 unsigned* __restrict__ sums,
@@ -307,8 +365,21 @@ void launch_kmeans_accumulate(const SiftPair* pairs, int nimages, const int64_t*
                               int nwords, unsigned* sums, unsigned* counts, hipStream_t s)
 {
     if (nimages <= 0) return;
-    hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3(64, nimages), dim3(256), 0, s, pairs, offsets, words, nwords,
-                       sums, counts);
+    const int lds = (kSumWords * kDescDim + kSumWords) * 4;
+    static DeviceFlags attr_set;   // the attribute is per device
+    if (first_launch_on_device(attr_set))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_accumulate_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int ranges = (nwords + kSumWords - 1) / kSumWords;
+    if (ranges > 64) {   // every workgroup reads the words of its images once per range: too much for large vocabularies
+        hipLaunchKernelGGL(kmeans_accumulate_rows_kernel, dim3(64, nimages), dim3(256), 0, s, pairs, offsets, words, nwords,
+                           sums, counts);
+        return;
+    }
+    // enough workgroups to fill the chip, few enough that the partial sums they add to memory stay small
+    const int slices = std::max(1, std::min(nimages, (1024 + ranges - 1) / ranges));
+    hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3(ranges, slices), dim3(512), lds, s, pairs, nimages, offsets, words,
+                       nwords, sums, counts);
 }
 
 void launch_kmeans_update(const unsigned* sums, const unsigned* counts, int nwords, uint8_t* words,
