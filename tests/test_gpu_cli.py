@@ -188,3 +188,26 @@ def test_cli_pairs_from_a_vocabulary(tmp_path, own_words):
         m0, _ = orc.match_dense_u8(images[a], images[b], orc.params((4, 5), True))
         expect.append(orc.matchtxt_record("%d.jpg" % a, "%d.jpg" % b, m0))
     assert open(out).read() == "".join(expect)
+
+
+def test_cli_explicit_pair_list(tmp_path):
+    """--pairs-file: pairs in file order, repeats and (j, i) after (i, j) allowed; bad lists are refused."""
+    sizes = [300, 200, 0, 450, 128]
+    imgs = _make_images(tmp_path, sizes, seed=23)
+    wanted = [(3, 0), (0, 3), (1, 4), (1, 4), (2, 1), (4, 4)]
+    lst = tmp_path / "pairs.txt"
+    lst.write_text("".join("%d %d\n" % p for p in wanted))
+    out = str(tmp_path / "m.txt")
+    res = subprocess.run([CLI, "--sift-dir", str(tmp_path), "--num", "5", "--out", out, "--pairs-file", str(lst), "--batch", "4"],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    expect = []
+    for a, b in wanted:
+        m0, _ = orc.match_dense_u8(imgs[a], imgs[b], orc.params((4, 5), True))
+        expect.append(orc.matchtxt_record("%d.jpg" % a, "%d.jpg" % b, m0))
+    assert open(out).read() == "".join(expect)
+    for bad in ("0 9\n", "0 1\n2\n", "a b\n"):
+        lst.write_text(bad)
+        res = subprocess.run([CLI, "--sift-dir", str(tmp_path), "--num", "5", "--out", out, "--pairs-file", str(lst)],
+                             capture_output=True, text=True, timeout=120)
+        assert res.returncode == 1, bad

@@ -28,6 +28,7 @@ struct Options {
     bool by_vocab = false;        // pair list from a visual vocabulary (vsm_shortlist_pairs)
     int vocab_size = 4096, topk = 20, kmeans = 0, kmeans_stride = 1;
     std::string vocab_file;       // .sift file whose descriptors are the words; empty: rows drawn from the images
+    std::string pairs_file;       // explicit pair list: one "i j" per line
     int consecutive = 3;
     std::vector<int32_t> discrete{7, 15};
     int ratio_num = 4, ratio_den = 5;
@@ -47,6 +48,7 @@ void usage()
             "  --append              append to FILE instead of starting it\n"
             "  --pairs exhaustive|window|vocab   all i<j pairs (default), the reference's window list, or every\n"
             "                        image's --topk most similar images by visual-word histograms\n"
+            "  --pairs-file FILE     the pair list itself: one \"i j\" (image numbers) per line, matched in file order\n"
             "  --topk T              vocab list: partners chosen per image (default 20)\n"
             "  --vocab FILE.sift     vocab list: the words; without it --vocab-size K (default 4096) rows are\n"
             "                        taken from the images themselves, evenly spread\n"
@@ -92,6 +94,7 @@ bool parse(int argc, char** argv, Options& o)
             o.by_vocab = strcmp(v, "vocab") == 0;
             o.exhaustive = !o.by_vocab && strcmp(v, "window") != 0;
         }
+        else if (a == "--pairs-file") { if (!(v = next("--pairs-file"))) return false; o.pairs_file = v; }
         else if (a == "--topk") { if (!(v = next("--topk"))) return false; o.topk = atoi(v); }
         else if (a == "--vocab") { if (!(v = next("--vocab"))) return false; o.vocab_file = v; }
         else if (a == "--kmeans-stride") { if (!(v = next("--kmeans-stride"))) return false; o.kmeans_stride = atoi(v); }
@@ -225,7 +228,32 @@ int main(int argc, char** argv)
     // ---- pair list
     std::vector<int32_t> pairs;
     long long npairs;
-    if (o.by_vocab) {
+    if (!o.pairs_file.empty()) {
+        FILE* fp = fopen(o.pairs_file.c_str(), "r");
+        if (!fp) {
+            fprintf(stderr, "cannot open %s\n", o.pairs_file.c_str());
+            return 1;
+        }
+        long long a = 0, b = 0;
+        int got;
+        while ((got = fscanf(fp, "%lld %lld", &a, &b)) == 2) {
+            if (a < 0 || b < 0 || a >= o.num || b >= o.num) {
+                fprintf(stderr, "%s: pair %lld %lld names an image outside 0..%d\n", o.pairs_file.c_str(), a, b, o.num - 1);
+                fclose(fp);
+                return 1;
+            }
+            pairs.push_back((int32_t)a);
+            pairs.push_back((int32_t)b);
+        }
+        const bool clean = got == EOF && feof(fp);
+        fclose(fp);
+        if (!clean) {
+            fprintf(stderr, "%s: not a list of \"i j\" lines\n", o.pairs_file.c_str());
+            return 1;
+        }
+        npairs = (long long)pairs.size() / 2;
+        pairs.resize((size_t)npairs * 2 + 2);
+    } else if (o.by_vocab) {
         if (o.vocab_file.empty() && o.kmeans > 0) {
             words.resize((size_t)o.vocab_size * VSM_DESC_DIM_U8);
             int k;
