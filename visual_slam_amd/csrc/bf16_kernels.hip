@@ -739,10 +739,7 @@ static void launch_coarse_t(const CoarseProblem* d_probs, int nprobs, int blocks
 {
     const int lds = 2 * kCoarseStepBytes;
     static DeviceFlags attr_set;   // the attribute is per device
-    if (first_launch_on_device(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_coarse_kernel<DIMP>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    }
+    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(bf16_coarse_kernel<DIMP>), lds);
     hipLaunchKernelGGL(bf16_coarse_kernel<DIMP>, dim3(blocks), dim3(kCoarseWaves * 64), lds, s,
                        d_probs, nprobs, part, lists, overflow);
 }

@@ -2,19 +2,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 namespace vsm {
 
-// Function attributes (dynamic LDS size) are set once per device a kernel is launched on.
+// A kernel that takes more dynamic LDS than the default limit needs the limit raised once per device it
+// is launched on.  The flag is set after the attribute, so a second thread never launches in between
+// (two threads may both set the attribute: harmless).
 struct DeviceFlags {
-    bool seen[64] = {};
+    std::atomic<bool> seen[64] = {};
 };
-inline bool first_launch_on_device(DeviceFlags& f)
+inline void ensure_dynamic_lds(DeviceFlags& f, const void* kernel, int bytes)
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-    if (f.seen[dev]) return false;
-    f.seen[dev] = true;
-    return true;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    if (known && f.seen[dev].load(std::memory_order_acquire)) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (known) f.seen[dev].store(true, std::memory_order_release);
 }
 
 }  // namespace vsm

@@ -323,10 +323,7 @@ static void launch_knn_t(const F32Problem& pr, int nstrips, int nsplits, int tps
 {
     const int lds = 2 * 32 * DIMP * 4 + 512;
     static DeviceFlags attr_set;   // the attribute is per device
-    if (first_launch_on_device(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f32_knn_kernel<DIMP>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    }
+    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(f32_knn_kernel<DIMP>), lds);
     hipLaunchKernelGGL(f32_knn_kernel<DIMP>, dim3(nstrips * nsplits), dim3(512), lds, s,
                        pr, nstrips, tps, qpart, colpart);
 }

@@ -559,10 +559,7 @@ void launch_geom_verify(const GeomPair* pairs, int npairs, int max_matches, cons
     const int gx = std::max(1, std::min(64, (max_matches + 255) / 256));
     hipLaunchKernelGGL(geom_gather_kernel, dim3(gx, npairs), dim3(256), 0, s, pairs, npairs, idx0, idx1, coords);
     static DeviceFlags attr_set;   // the attribute is per device
-    if (first_launch_on_device(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(geom_solve_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)geom_lds_bytes());
-    }
+    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(geom_solve_kernel), (int)geom_lds_bytes());
     hipLaunchKernelGGL(geom_solve_kernel, dim3((rule.hypotheses + kGeomThreads - 1) / kGeomThreads, npairs),
                        dim3(kGeomThreads), geom_lds_bytes(), s, pairs, coords, rule, Fh);
     hipLaunchKernelGGL(geom_score_kernel, dim3(npairs), dim3(kGeomScoreThreads), 0, s,

@@ -367,9 +367,7 @@ void launch_kmeans_accumulate(const SiftPair* pairs, int nimages, const int64_t*
     if (nimages <= 0) return;
     const int lds = (kSumWords * kDescDim + kSumWords) * 4;
     static DeviceFlags attr_set;   // the attribute is per device
-    if (first_launch_on_device(attr_set))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_accumulate_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(kmeans_accumulate_kernel), lds);
     const int ranges = (nwords + kSumWords - 1) / kSumWords;
     if (ranges > 64) {   // every workgroup reads the words of its images once per range: too much for large vocabularies
         hipLaunchKernelGGL(kmeans_accumulate_rows_kernel, dim3(64, nimages), dim3(256), 0, s, pairs, offsets, words, nwords,

@@ -286,10 +286,7 @@ void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
                        int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, hipStream_t s)
 {
     static DeviceFlags attr_set;   // the attribute is per device
-    if (first_launch_on_device(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sift_query_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsStream);
-    }
+    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(sift_query_kernel), kLdsStream);
     hipLaunchKernelGGL(sift_query_kernel, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
                        pairs, items, rr_d1, rr_j1, rr_d2, -512);
 }
@@ -458,10 +455,7 @@ void launch_sift_verify(const SiftPair* pairs, int npairs, SiftItem* vitems, int
     if (npairs <= 0 || max_vitems <= 0) return;
     hipLaunchKernelGGL(sift_verify_plan_kernel, dim3(1), dim3(1024), 0, s, cand.count, npairs, vitems, nvitems);
     static DeviceFlags attr_set;   // the attribute is per device
-    if (first_launch_on_device(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sift_verify_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsStream);
-    }
+    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(sift_verify_kernel), kLdsStream);
     hipLaunchKernelGGL(sift_verify_kernel, dim3(kVerifyGrid), dim3(kVerifyWaves * 64), kLdsStream, s,
                        pairs, vitems, nvitems, cand, -512);
 }
