@@ -206,6 +206,9 @@ def test_cli_explicit_pair_list(tmp_path):
         m0, _ = orc.match_dense_u8(imgs[a], imgs[b], orc.params((4, 5), True))
         expect.append(orc.matchtxt_record("%d.jpg" % a, "%d.jpg" % b, m0))
     assert open(out).read() == "".join(expect)
+    res = subprocess.run([CLI, "--sift-dir", str(tmp_path), "--num", "5", "--out", out, "--mat", "--shard", "0/2"],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 2 and "--mat cannot be combined" in res.stderr   # slices share the .mat files
     for bad in ("0 9\n", "0 1\n2\n", "a b\n"):
         lst.write_text(bad)
         res = subprocess.run([CLI, "--sift-dir", str(tmp_path), "--num", "5", "--out", out, "--pairs-file", str(lst)],

@@ -133,6 +133,12 @@ bool parse(int argc, char** argv, Options& o)
         }
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
     }
+    if (o.write_mat && o.nshards > 1) {
+        // every slice would update the records of the same <image>.mat files, and the writer keeps their
+        // directories in memory until it closes
+        fprintf(stderr, "--mat cannot be combined with --shard: write the .mat records from one process\n");
+        return false;
+    }
     if (!o.inlier_out.empty() && !(o.verify > 0.0f)) {
         fprintf(stderr, "--inlier-out needs --verify\n");
         return false;
