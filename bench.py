@@ -14,6 +14,8 @@ is no data-path collective.  Rank 0 prints one JSON line.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -84,7 +86,62 @@ def parse():
                     help="float workloads: 0 = bf16 coarse pass + exact re-rank, 1 = f32-input MFMA kernel only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the check of a sample of the timed run's output against the CPU oracle")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: start the ranks, build the pair list / database slices, exchange the shard "
+                         "bookkeeping over gloo and print it (what the CPU test of the launcher runs)")
     return ap.parse_args()
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous shard [lo, hi) of n items for `rank` of `world`; the shards differ by at most one item
+    and cover every item exactly once."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def host_threads():
+    """Threads for the CPU baseline: every CPU this process may run on, unless OMP_NUM_THREADS (the
+    box's CPU share) says fewer.  Returns (threads, cpus available to the process)."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    env = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    return (max(1, min(env, avail)) if env > 0 else avail), avail
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: this process touches no GPU (it does not
+    even import torch); it starts N fresh children, one rank per GPU, with the rendezvous variables
+    torch.distributed.run would set, relays rank 0's JSON line and fails if any rank fails."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(args.gpus))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+                for o in pending:           # the others would wait in a barrier for ever
+                    procs[o].terminate()
+        if pending:
+            time.sleep(0.05)
+    out = procs[0].stdout.read().decode()
+    if rc == 0:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    return rc
 
 
 def dist_setup(args):
@@ -94,6 +151,11 @@ def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        return torch, dist, world, rank, local
     # Rehearsal of the multi-rank path on a one-GPU box: VSM_BENCH_REHEARSAL=1 puts every rank on
     # device 0 and runs the collectives over gloo on host tensors (RCCL refuses two ranks per GPU).
     global REHEARSAL
@@ -171,8 +233,7 @@ def cpu_baseline_u8(sets, budget_s):
     like the GPU's."""
     import oracle_lib as orc
 
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-    threads = max(1, min(threads, os.cpu_count() or 1))
+    threads, avail = host_threads()
     orc.knn2_u8(sets[0][:256], sets[1], threads)  # page in, spin up the thread pool
     evals = 0
     npairs = 0
@@ -187,7 +248,7 @@ def cpu_baseline_u8(sets, budget_s):
         if dt >= budget_s or npairs >= 4096:
             break
     return {
-        "value": evals / dt / 1e9, "unit": "G evals/s", "cores": threads, "kind": "port",
+        "value": evals / dt / 1e9, "unit": "G evals/s", "cores": threads, "host_cpus": avail, "kind": "port",
         "sample": "oracle 2-NN, %d pairs of %d x %d SIFT-128 u8 from the same arena, %.1f s"
                   % (npairs, len(sets[0]), len(sets[1]), dt),
     }
@@ -202,8 +263,8 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
     ids = [m.upload_u8_device(arena[i].data_ptr(), nfeat) for i in range(nimg)]
     pairs_all = vsm.generate_exhaustive_pairs(nimg)
     # contiguous shard per rank: consecutive pairs share image 0, so it stays cache-resident
-    per = len(pairs_all) // world
-    shard = pairs_all[rank * per:(rank + 1) * per]
+    lo, hi = shard_bounds(len(pairs_all), world, rank)
+    shard = pairs_all[lo:hi]
     id_arr = np.asarray(ids, np.int32)
 
     # A step = one GPU submission of `pps` pairs through the whole path, match lists copied to the
@@ -215,6 +276,8 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
 
     cap = pps * nfeat
     bufs = [(np.empty(pps + 1, np.int64), np.empty(cap, np.int32), np.empty(cap, np.int32)) for _ in range(2)]
+
+    last = {}
 
     def run(first, count):
         npairs = nmatch = 0
@@ -229,6 +292,7 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
             nmatch += int(off[-1])
             kms.append(m.last_kernel_ms())   # brackets of the submission just collected
             vms.append(m.last_verify_ms())
+            last.update(step=first + k, off=off, i0=i0, i1=i1)
         return npairs, nmatch, kms, vms
 
     m.set_timing(True)
@@ -239,6 +303,21 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
     barrier_sync(torch, dist, world)
     dt = max_over_ranks(torch, dist, world, time.perf_counter() - t0)
     total_pairs = sum_over_ranks(torch, dist, world, npairs)
+    verified = None
+    if not args.no_verify and last:
+        # outside the timed region: three pairs of the last timed submission, exactly the lists the
+        # timed run copied to the host, against the CPU oracle on the same descriptors
+        import oracle_lib as orc
+        threads, _ = host_threads()
+        lo_p = (last["step"] * pps) % max(len(shard) - pps + 1, 1)
+        step_pairs = shard[lo_p:lo_p + pps]
+        ok = True
+        for k in sorted({0, len(step_pairs) // 2, len(step_pairs) - 1}):
+            ia, ib = int(step_pairs[k][0]), int(step_pairs[k][1])
+            o0, o1, _ = orc.match_u8(arena[ia].cpu().numpy(), arena[ib].cpu().numpy(), orc.params((4, 5), True), threads)
+            a, b = int(last["off"][k]), int(last["off"][k + 1])
+            ok = ok and np.array_equal(last["i0"][a:b], o0) and np.array_equal(last["i1"][a:b], o1)
+        verified = bool(sum_over_ranks(torch, dist, world, 0 if ok else 1) == 0)
     evals = total_pairs * float(nfeat) * float(nfeat)
     kms = float(np.mean(kernel_ms))
     launch_pairs = m.last_submission_pairs()
@@ -249,7 +328,7 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
         "pairs_per_s": total_pairs / dt,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic", "verified": verified,
         "config": {"workload": "exhaustive SIFT-128 matching, %d images x %d features, ratio 0.8 + mutual, "
                                "%d pairs per step per GPU, two steps in flight, match lists copied to host"
                                % (nimg, nfeat, pps),
@@ -257,6 +336,8 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
                    "matches_per_pair": nmatch / max(npairs, 1)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                      "frac": achieved / INT8_DENSE_PEAK_TOPS,
+                     "frac_step": OPS_PER_EVAL_U8 * float(pps) * nfeat * nfeat / (dt / args.steps) / 1e12
+                                  / INT8_DENSE_PEAK_TOPS,
                      "traffic": measured_traffic("vsm::sift_query_kernel")
                      if (nimg, nfeat, launch_pairs) == (1000, 8192, 2048) else None,
                      "mfma_busy_frac": measured_mfma_busy("vsm::sift_query_kernel")
@@ -304,24 +385,31 @@ def run_superpoint_pair(args, torch, dist, world, rank):
     dt = max_over_ranks(torch, dist, world, time.perf_counter() - t0)
     evals = float(world) * args.steps * n * n
     kms = float(np.mean(kernel_ms))
+    verified = None
+    if not args.no_verify:
+        import oracle_lib as orc
+        o0, o1, _, _ = orc.match_dense_f32(a, b, orc.METRIC_DOT, orc.params(None, True), host_threads()[0])
+        ok = np.array_equal(m0, o0) and np.array_equal(m1, o1)
+        verified = bool(sum_over_ranks(torch, dist, world, 0 if ok else 1) == 0)
     out = {
         "metric": "descriptor distance evals/sec", "value": evals / dt / 1e9, "unit": "G/s",
         "pairs_per_s": world * args.steps / dt,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "verified": verified,
         "config": {"workload": "SuperPoint-256 f32, 2 images x 4096 keypoints, mutual-NN, one pair per step",
                    "parallelism": "replicas x%d" % world, "matches": int((m0 >= 0).sum())},
         "roofline": f32_roofline(m, OPS_PER_EVAL_F32 * float(n) * n, kms),
     }
     if world == 1 and not args.no_cpu_baseline:
         import oracle_lib as orc
-        threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0")) or 16, os.cpu_count() or 1))
+        threads, avail = host_threads()
         rows = 1024
         t0 = time.perf_counter()
         orc.knn2_f32(a[:rows], b, orc.METRIC_DOT, threads)
         c = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": rows * n / c / 1e9, "unit": "G evals/s", "cores": threads, "kind": "port",
+        out["cpu_baseline"] = {"value": rows * n / c / 1e9, "unit": "G evals/s", "cores": threads, "host_cpus": avail,
+                               "kind": "port",
                                "sample": "oracle 2-NN, %d x %d float-256, %.1f s" % (rows, n, c)}
     m.close()
     return out
@@ -337,6 +425,7 @@ def run_superpoint_pairs(args, torch, dist, world, rank):
     g.manual_seed(555)
     pool = torch.randn((n, 256), generator=g, device="cuda")
     ids = []
+    keep = {}
     m = vsm.Matcher(torch.cuda.current_device())
     for i in range(nimg):
         x = torch.randn((n, 256), generator=g, device="cuda")
@@ -347,18 +436,20 @@ def run_superpoint_pairs(args, torch, dist, world, rank):
         x /= x.norm(dim=1, keepdim=True)
         torch.cuda.synchronize()
         ids.append(m.upload_f32_device(x.data_ptr(), n, 256))
+        keep[i] = x.cpu().numpy()
     m.set_timing(True)
     m.set_f32_mode(args.f32_mode)
     pairs_all = vsm.generate_exhaustive_pairs(nimg)
-    per = (len(pairs_all) + world - 1) // world
-    mine = pairs_all[rank * per:(rank + 1) * per]
+    lo_s, hi_s = shard_bounds(len(pairs_all), world, rank)
+    mine = pairs_all[lo_s:hi_s]
     idmap = np.asarray(ids, np.int32)
+    last = {}
 
     def step(k):
         lo = (k * pps) % max(len(mine) - pps + 1, 1)
         pr = idmap[np.asarray(mine[lo:lo + pps], np.int64)]
         tot = m.match_pairs_device(pr, ratio=None, mutual=True, metric=vsm.METRIC_DOT, min_score=0.5)
-        m.fetch_matches(len(pr), tot)
+        last.update(pairs=mine[lo:lo + pps], lists=m.fetch_matches(len(pr), tot))
         return len(pr), tot
 
     for k in range(args.warmup):
@@ -375,12 +466,25 @@ def run_superpoint_pairs(args, torch, dist, world, rank):
     dt = max_over_ranks(torch, dist, world, time.perf_counter() - t0)
     total_pairs = sum_over_ranks(torch, dist, world, npairs)
     kms = float(np.mean(kernel_ms))
+    verified = None
+    if not args.no_verify and last:
+        import oracle_lib as orc
+        off, i0, i1 = last["lists"]
+        ok = True
+        for k in sorted({0, len(last["pairs"]) - 1}):
+            ia, ib = int(last["pairs"][k][0]), int(last["pairs"][k][1])
+            o0, _, _, _ = orc.match_dense_f32(keep[ia], keep[ib], orc.METRIC_DOT, orc.params(None, True, min_score=0.5),
+                                              host_threads()[0])
+            sel = np.nonzero(o0 >= 0)[0].astype(np.int32)
+            lo, hi = int(off[k]), int(off[k + 1])
+            ok = ok and np.array_equal(i0[lo:hi], sel) and np.array_equal(i1[lo:hi], o0[sel])
+        verified = bool(sum_over_ranks(torch, dist, world, 0 if ok else 1) == 0)
     out = {
         "metric": "descriptor distance evals/sec", "value": total_pairs * float(n) * n / dt / 1e9, "unit": "G/s",
         "pairs_per_s": total_pairs / dt,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "verified": verified,
         "config": {"workload": "exhaustive SuperPoint-256 f32 matching, %d images x %d keypoints, mutual-NN, "
                                "%d pairs per step per GPU, match lists copied to host" % (nimg, n, pps),
                    "parallelism": "pair list sharded x%d" % world, "matches_per_pair": nmatch / max(npairs, 1)},
@@ -401,9 +505,11 @@ def run_sift_large_pair(args, torch, dist, world, rank):
     m.set_timing(True)
     pr = np.asarray([[ids[0], ids[1]]], np.int32)
 
+    last = {}
+
     def step():
         tot = m.match_pairs_device(pr, ratio=0.8, mutual=True)
-        m.fetch_matches(1, tot)
+        last["lists"] = m.fetch_matches(1, tot)
         return tot
 
     for _ in range(args.warmup):
@@ -419,12 +525,19 @@ def run_sift_large_pair(args, torch, dist, world, rank):
     evals = float(world) * args.steps * n * n
     kms = float(np.mean(kernel_ms))
     achieved = OPS_PER_EVAL_U8 * float(n) * n / (kms * 1e-3) / 1e12
+    verified = None
+    if not args.no_verify and last:
+        import oracle_lib as orc
+        o0, o1, _ = orc.match_u8(arena[0].cpu().numpy(), arena[1].cpu().numpy(), orc.params((4, 5), True),
+                                 host_threads()[0])
+        ok = np.array_equal(last["lists"][1], o0) and np.array_equal(last["lists"][2], o1)
+        verified = bool(sum_over_ranks(torch, dist, world, 0 if ok else 1) == 0)
     out = {
         "metric": "descriptor distance evals/sec", "value": evals / dt / 1e9, "unit": "G/s",
         "pairs_per_s": world * args.steps / dt,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic", "verified": verified,
         "config": {"workload": "one SIFT-128 pair of 65536 x 65536 features, ratio 0.8 + mutual",
                    "parallelism": "replicas x%d" % world, "matches": int(tot)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
@@ -606,12 +719,26 @@ def run_db_query(args, torch, dist, world, rank):
     dt = max_over_ranks(torch, dist, world, time.perf_counter() - t0)
     evals = float(args.steps) * nq * ndb
     kms = float(np.mean(kernel_ms))
+    verified = None
+    if not args.no_verify:
+        # every rank: a 64-query sample of its slice's 2-NN (the words that go into the all-gather) against
+        # the oracle over the whole slice; with one rank the merged global lists as well
+        import oracle_lib as orc
+        sample = np.arange(0, nq, nq // 64)[:64]
+        qs = q[torch.as_tensor(sample, device="cuda")].cpu().numpy()
+        oi, ok1, ok2 = orc.knn2_f32(qs, db.cpu().numpy(), orc.METRIC_L2, host_threads()[0])
+        pk = pack.cpu().numpy()
+        ok = (np.array_equal(pk[2][sample], oi) and np.array_equal(pk[0][sample].view(np.float32), ok1)
+              and np.array_equal(pk[1][sample].view(np.float32), ok2))
+        if world == 1:
+            ok = ok and np.array_equal(res[2][sample], oi.astype(np.int64)) and np.array_equal(res[0][sample], ok1)
+        verified = bool(sum_over_ranks(torch, dist, world, 0 if ok else 1) == 0)
     out = {
         "metric": "descriptor distance evals/sec", "value": evals / dt / 1e9, "unit": "G/s",
         "queries_per_s": args.steps * nq / dt,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "verified": verified,
         "config": {"workload": "16384 float-256 queries vs 1M-row database, k=2, L2",
                    "parallelism": "database sliced x%d, RCCL all-gather of the per-slice 2-NN lists, device merge" % world},
         "roofline": f32_roofline(m, OPS_PER_EVAL_F32 * float(nq) * (hi - lo), kms),
@@ -622,9 +749,39 @@ def run_db_query(args, torch, dist, world, rank):
     return out
 
 
+def run_dry(args, torch, dist, world, rank):
+    """The rank / shard bookkeeping of the sharded workloads without a GPU: every rank derives its own
+    shard exactly as the real run does, the shards are all-gathered and rank 0 reports them."""
+    import visual_slam_amd as vsm
+
+    if args.workload == "db_query":
+        n = 1000000
+        per = (n + world - 1) // world
+        mine = [min(n, rank * per), min(n, (rank + 1) * per)]
+    else:
+        n = len(vsm.generate_exhaustive_pairs(args.images if args.workload == "sift_exhaustive" else 64))
+        mine = list(shard_bounds(n, world, rank))
+    shards = [None] * world
+    if world > 1:
+        dist.all_gather_object(shards, [rank] + mine)
+    else:
+        shards = [[rank] + mine]
+    return {"dry_run": True, "workload": args.workload, "n_gpus": world, "items": n,
+            "shards": [[int(v) for v in sh] for sh in shards]}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     torch, dist, world, rank, local = dist_setup(args)
+    if args.dry_run:
+        out = run_dry(args, torch, dist, world, rank)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     fn = {"sift_exhaustive": run_sift_exhaustive, "superpoint_pair": run_superpoint_pair,
           "superpoint_pairs": run_superpoint_pairs,
           "sift_large_pair": run_sift_large_pair, "db_query": run_db_query, "geom_verify": run_geom_verify,

@@ -81,3 +81,41 @@ def test_world_size_two(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def _dry(args):
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"] + args, env=env,
+                         stdout=subprocess.PIPE, check=True, timeout=300).stdout.decode()
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out           # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_launcher_spawns_ranks_and_shards_every_pair():
+    """`bench.py --gpus 2` with no launcher around it starts two ranks itself; their shards of the pair
+    list are contiguous, differ by at most one pair and cover every pair (253 pairs: an odd count)."""
+    r = _dry(["--gpus", "2", "--images", "23"])
+    assert r["n_gpus"] == 2 and r["items"] == 253
+    assert r["shards"] == [[0, 0, 126], [1, 126, 253]]
+    r = _dry(["--gpus", "3", "--workload", "db_query"])
+    assert r["n_gpus"] == 3
+    assert [s[1:] for s in r["shards"]] == [[0, 333334], [333334, 666668], [666668, 1000000]]
+    r = _dry(["--images", "23"])
+    assert r["n_gpus"] == 1 and r["shards"] == [[0, 0, 253]]
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", "2", "--images", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    # one image has no pairs: generate_exhaustive_pairs(1) is empty but valid, so this still succeeds
+    assert p.returncode == 0
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", "2", "--images", "-5"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and not p.stdout.strip()
