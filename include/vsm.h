@@ -72,12 +72,14 @@ void* vsm_stream(vsm_ctx* ctx);
 /* SIFT descriptors as FeatureData::ReadSIFTB(file, locbuf, desbuf, nmax) hands them
  * over (FeaturePoints.cpp:516-531): row-major uint8 [n][128].  Returns a set id. */
 int vsm_upload_u8(vsm_ctx* ctx, const uint8_t* des, int n);
-/* Same, from a device pointer on the context's device (no host round trip). */
+/* Same, from a device pointer on the context's device (no host round trip).  The buffer must be
+ * 16-byte aligned (VSM_EINVAL otherwise); it may be reused as soon as the call returns. */
 int vsm_upload_u8_device(vsm_ctx* ctx, const void* des_dev, int n);
 /* SuperPoint-style float descriptors.  VSM_LAYOUT_DIM_MAJOR is the reference's
  * native [256][N] tensor (superpoint.py:196-202), VSM_LAYOUT_ROWS the transposed
  * form main.py:255 makes.  1 <= dim <= 256. */
 int vsm_upload_f32(vsm_ctx* ctx, const float* des, int n, int dim, int layout);
+/* From a device pointer on the context's device, either layout; 4-byte aligned. */
 int vsm_upload_f32_device(vsm_ctx* ctx, const void* des_dev, int n, int dim, int layout);
 /* How float sets are searched.  Both modes return the same bits: scores are the
  * k-ascending single-precision fma chain, ties go to the lowest index (the torch

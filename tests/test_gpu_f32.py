@@ -331,3 +331,90 @@ def test_device_merge_equals_host_merge(matcher):
     finally:
         hip.hipFree(dev)
         matcher.release(sq)
+
+
+def _float_images(rng, sizes, dim):
+    pool = synth.unit_f32(300, dim, rng)
+    imgs = []
+    for n in sizes:
+        d = synth.unit_f32(max(n, 1), dim, rng)[:n]
+        k = min(n, 300) // 2
+        if k:
+            noisy = pool[rng.choice(300, k, replace=False)] + 0.8 / math.sqrt(dim) * rng.standard_normal((k, dim)).astype(np.float32)
+            d[rng.choice(n, k, replace=False)] = noisy / np.linalg.norm(noisy, axis=1, keepdims=True)
+        imgs.append(np.ascontiguousarray(d, np.float32))
+    return imgs
+
+
+def _check_float_pair_lists(imgs, pairs, off, i0, i1, metric, fr, mutual):
+    total = 0
+    for k, (a, b) in enumerate(pairs):
+        o0, _, _, _ = orc.match_dense_f32(imgs[a], imgs[b], metric, orc.params(fr, mutual, min_score=0.5))
+        want0 = np.nonzero(o0 >= 0)[0]
+        np.testing.assert_array_equal(i0[off[k]:off[k + 1]], want0)
+        np.testing.assert_array_equal(i1[off[k]:off[k + 1]], o0[want0])
+        total += len(want0)
+    assert off[-1] == total
+    return total
+
+
+def test_float_pair_list_cut_by_scratch_budget(matcher):
+    """A float pair list that does not fit one submission's scratch: match_pairs cuts it and runs the
+    submissions one after the other; the lists equal the oracle's pair by pair."""
+    rng = np.random.default_rng(71)
+    sizes = [700, 513, 900, 300, 1100]
+    imgs = _float_images(rng, sizes, 256)
+    ids = [matcher.upload_f32(d) for d in imgs]
+    pairs = [(a, b) for a in range(len(sizes)) for b in range(len(sizes)) if a != b]
+    pr = np.asarray([[ids[a], ids[b]] for a, b in pairs], np.int32)
+    matcher.set_scratch_budget(8 << 20)       # a few pairs per submission at most
+    try:
+        for metric, ratio, mutual in ((vsm.METRIC_DOT, None, True), (vsm.METRIC_L2, 0.8, True)):
+            off, i0, i1 = matcher.match_pairs(pr, ratio=ratio, mutual=mutual, metric=metric, min_score=0.5)
+            fr = None if ratio is None else tuple(B.ratio_to_fraction(ratio))
+            assert _check_float_pair_lists(imgs, pairs, off, i0, i1, metric, fr, mutual) > 200
+    finally:
+        matcher.set_scratch_budget(8 << 30)
+        for sid in ids:
+            matcher.release(sid)
+
+
+def test_more_float_pairs_than_one_submission_takes(matcher):
+    """More than 8192 tiny float pairs in one call: cut by the pair-count limit of a submission."""
+    rng = np.random.default_rng(72)
+    sizes = [40, 33, 57, 1, 64]
+    imgs = _float_images(rng, sizes, 64)
+    ids = [matcher.upload_f32(d) for d in imgs]
+    base = [(a, b) for a in range(len(sizes)) for b in range(len(sizes)) if a != b]
+    pairs = (base * (9000 // len(base) + 1))[:9000]
+    pr = np.asarray([[ids[a], ids[b]] for a, b in pairs], np.int32)
+    off, i0, i1 = matcher.match_pairs(pr, ratio=None, mutual=True, metric=vsm.METRIC_DOT, min_score=0.5)
+    want = {}
+    for k, (a, b) in enumerate(pairs):
+        if (a, b) not in want:
+            o0, _, _, _ = orc.match_dense_f32(imgs[a], imgs[b], vsm.METRIC_DOT, orc.params(None, True, min_score=0.5))
+            sel = np.nonzero(o0 >= 0)[0]
+            want[(a, b)] = (sel, o0[sel])
+        np.testing.assert_array_equal(i0[off[k]:off[k + 1]], want[(a, b)][0])
+        np.testing.assert_array_equal(i1[off[k]:off[k + 1]], want[(a, b)][1])
+    for sid in ids:
+        matcher.release(sid)
+
+
+def test_config2_shape_4096_mutual(matcher):
+    """2 images x 4096 SuperPoint-256 descriptors, mutual nearest neighbour on the dot product: the
+    launch the single-pair benchmark times (two searches + accept), dense and list forms."""
+    a, b = synth.superpoint_pair(4096, 4096, 256, seed=77)
+    s0, s1 = matcher.upload_f32(a), matcher.upload_f32(b)
+    try:
+        o0, o1, _, _ = orc.match_dense_f32(a, b, orc.METRIC_DOT, orc.params(None, True))
+        g0, g1 = matcher.match_pair_dense(s0, s1, ratio=None, mutual=True, metric=vsm.METRIC_DOT)
+        np.testing.assert_array_equal(g0, o0)
+        np.testing.assert_array_equal(g1, o1)
+        i0, i1 = matcher.match_pair(s0, s1, ratio=None, mutual=True, metric=vsm.METRIC_DOT)
+        np.testing.assert_array_equal(i0, np.nonzero(o0 >= 0)[0])
+        np.testing.assert_array_equal(i1, o0[o0 >= 0])
+        assert (o0 >= 0).sum() > 1000
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)

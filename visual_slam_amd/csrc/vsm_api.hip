@@ -488,6 +488,9 @@ static int upload_u8_common(vsm_ctx* c, const void* src, int n, bool src_on_devi
     if (n < 0 || (n > 0 && !src)) return fail(c, VSM_EINVAL, "bad descriptor buffer (n=%d)", n);
     // work items name blocks of kVerifyBlock rows in 16 bits
     if (n > 32767 * kVerifyBlock) return fail(c, VSM_EINVAL, "a u8 set holds at most %d rows (got %d)", 32767 * kVerifyBlock, n);
+    // the transform kernel reads the rows with 16-byte loads (host buffers go through an aligned staging copy)
+    if (src_on_device && n > 0 && (reinterpret_cast<uintptr_t>(src) & 15) != 0)
+        return fail(c, VSM_EINVAL, "device descriptor buffer %p is not 16-byte aligned", src);
     HIPCHK(c, hipSetDevice(c->device));
     DescSet s;
     s.kind = SET_U8;
@@ -536,6 +539,8 @@ static int upload_f32_common(vsm_ctx* c, const void* src, int n, int dim, int la
     if (n < 0 || (n > 0 && !src)) return fail(c, VSM_EINVAL, "bad descriptor buffer (n=%d)", n);
     if (dim <= 0 || dim > 256) return fail(c, VSM_EINVAL, "dim %d must be in 1..256", dim);
     if (layout != VSM_LAYOUT_ROWS && layout != VSM_LAYOUT_DIM_MAJOR) return fail(c, VSM_EINVAL, "unknown layout %d", layout);
+    if (src_on_device && n > 0 && (reinterpret_cast<uintptr_t>(src) & 3) != 0)
+        return fail(c, VSM_EINVAL, "device descriptor buffer %p is not 4-byte aligned", src);
     HIPCHK(c, hipSetDevice(c->device));
     DescSet s;
     s.kind = SET_F32;
@@ -1144,9 +1149,13 @@ extern "C" long long vsm_match_pairs(vsm_ctx* c, const int32_t* pairs, int npair
         (void)hipStreamSynchronize(c->copy_stream);
         c->inflight = 0;
     };
-    if (nsub > 0 && (rc = submit(0)) != VSM_OK) return rc;
+    // Float submissions are searched inside submit (the survivor-overflow check needs the result) and
+    // cannot queue behind one another: they run one after the other, submit(k) then collect(k).
+    const DescSet* first = npairs > 0 ? get_set(c, pairs[0]) : nullptr;
+    const bool pipelined = !(first && first->kind == SET_F32);
+    if (pipelined && nsub > 0 && (rc = submit(0)) != VSM_OK) return rc;
     for (int k = 0; k < nsub; ++k) {
-        if (k + 1 < nsub && (rc = submit(k + 1)) != VSM_OK) {
+        if ((pipelined ? k + 1 < nsub && (rc = submit(k + 1)) != VSM_OK : (rc = submit(k)) != VSM_OK)) {
             drain();
             return rc;
         }
