@@ -106,6 +106,17 @@ int vsm_match_pair(vsm_ctx* ctx, int set0, int set1, const vsm_params* p, int me
 /* Dense form: matches0[n0], matches1[n1] with -1 (superglue.py:276-293). */
 int vsm_match_pair_dense(vsm_ctx* ctx, int set0, int set1, const vsm_params* p, int metric,
                          int32_t* matches0, int32_t* matches1);
+/* No counterpart in the reference.  vsm_match_pair for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): one pair of
+ * resident u8 sets, same match list, but every intermediate lives in a fixed 4 MiB array that the
+ * library holds once per GPU, the call makes no hipMalloc / hipFree / host-to-device copy, and the
+ * results go straight to the caller's DEVICE buffers: idx0_dev / idx1_dev (cap >= rows of set0 entries
+ * each; the first *count_dev are valid) and count_dev (one int32).  The work is queued on the context's
+ * stream (vsm_stream) and the call returns without waiting; VSM_ECAP when a set has more than 16384
+ * rows.  Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two
+ * contexts, two streams) race; calls on one context are ordered by its stream. */
+int vsm_match_pair_noalloc(vsm_ctx* ctx, int set0, int set1, const vsm_params* p,
+                           int32_t* idx0_dev, int32_t* idx1_dev, int32_t* count_dev, int cap);
 /* Many pairs in one submission (the per-pair loop of main.py:220-280).  pairs is
  * [npairs][2] set ids.  offsets[npairs+1] receives where each pair's matches start
  * in idx0/idx1 (cap entries each).  Returns the total or VSM_ECAP. */

@@ -59,6 +59,8 @@ SIGNATURES = {
     "vsm_set_count": (C.c_int, [C.c_void_p, C.c_int]),
     "vsm_match_pair": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "vsm_match_pair_noalloc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_int]),
     "vsm_match_pair_dense": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_int,
                                        C.c_void_p, C.c_void_p]),
     "vsm_match_pairs": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Params), C.c_int,
@@ -239,6 +241,13 @@ class Matcher:
         if return_dist:
             return idx0[:nm].copy(), idx1[:nm].copy(), dist[:nm].copy()
         return idx0[:nm].copy(), idx1[:nm].copy()
+
+    def match_pair_noalloc(self, set0, set1, idx0_dev, idx1_dev, count_dev, cap, ratio=0.8, mutual=True, max_dist_sq=-1):
+        """match_pair with all intermediates in the library's fixed per-GPU array and the lists written to
+        the caller's device buffers (raw device addresses); queued on the context's stream, not waited for."""
+        p = make_params(ratio, mutual, max_dist_sq)
+        self._check(self._l.vsm_match_pair_noalloc(self._h, set0, set1, C.byref(p), C.c_void_p(int(idx0_dev)),
+                                                   C.c_void_p(int(idx1_dev)), C.c_void_p(int(count_dev)), int(cap)))
 
     def match_pair_dense(self, set0, set1, ratio=0.8, mutual=True, max_dist_sq=-1, metric=METRIC_L2,
                          min_score=float("-inf"), max_dist_sq_f=-1.0):

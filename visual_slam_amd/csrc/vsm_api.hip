@@ -9,10 +9,24 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
 using namespace vsm;
+
+// Scratch of vsm_match_pair_noalloc: the device memory its kernels need beyond the caller's inputs and
+// outputs (pair record, work items, per-chunk partial results, candidate lists).  One copy per GPU,
+// held until the process ends.  Host code never passes this name to a kernel: g_scratch_ptr[device]
+// holds the array's address on that device (hipGetSymbolAddress, taken once per device in vsm_create).
+// File scope on purpose: the runtime cannot resolve a device variable declared inside an unnamed
+// namespace (hipGetSymbolAddress aborts with "Cannot create GlobalVar Obj").
+constexpr size_t kNoAllocScratchBytes = (size_t)4 << 20;
+constexpr int kNoAllocMaxRows = 16384;     // most rows per set of a vsm_match_pair_noalloc call
+constexpr int kMaxDevices = 256;
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[kMaxDevices] = {};
 
 namespace {
 
@@ -85,6 +99,7 @@ struct DescSet {
 struct vsm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    unsigned char* noalloc_scratch = nullptr;   // this device's copy of `scratch`
     std::string err;
     std::vector<DescSet> sets;
     // workspace (grow-only)
@@ -181,19 +196,28 @@ struct Plan {
     size_t rows = 0, out0 = 0, out1 = 0;
 };
 
+// Train rows per work item of the query pass.  A submission of few pairs (one pair per call is the
+// common case of a per-pair loop) is cut into narrower chunks of the train set, so that its query pass
+// still has a few hundred workgroups.  strips_total: query strips of the whole submission.
+int chunk_cols_for(long long strips_total, int nB_pad)
+{
+    const long long kWantItems = 256;
+    if (strips_total <= 0 || strips_total * ((nB_pad + kChunkCols - 1) / kChunkCols) >= kWantItems) return kChunkCols;
+    const long long want_chunks = (kWantItems + strips_total - 1) / strips_total;
+    const long long cols = ((long long)nB_pad + want_chunks - 1) / want_chunks;
+    return (int)std::min<long long>(kChunkCols, std::max<long long>(2 * kStepRows, (cols + kStepRows - 1) / kStepRows * kStepRows));
+}
+
 int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
 {
     pl.pairs.resize(npairs);
     pl.items.clear();
     pl.max_vitems = 0;
-    // A submission of few pairs (one pair per call is the common case of a per-pair loop) is cut into
-    // narrower chunks of the train set, so that its query pass still has a few hundred workgroups.
     long long strips_total = 0;
     for (int p = 0; p < npairs; ++p) {
         const DescSet* A = get_set(c, pairs[2 * p]);
         if (A && A->kind == SET_U8) strips_total += A->n_pad / kStripRows;
     }
-    const long long kWantItems = 256;
     for (int p = 0; p < npairs; ++p) {
         const DescSet* A = get_set(c, pairs[2 * p]);
         const DescSet* B = get_set(c, pairs[2 * p + 1]);
@@ -207,12 +231,7 @@ int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
         sp.nA = A->n; sp.nB = B->n; sp.nA_pad = A->n_pad; sp.nB_pad = B->n_pad;
         const bool empty = A->n == 0 || B->n == 0;
         sp.nstrips = empty ? 0 : A->n_pad / kStripRows;
-        int chunk_cols = kChunkCols;
-        if (!empty && strips_total * ((B->n_pad + kChunkCols - 1) / kChunkCols) < kWantItems) {
-            const long long want_chunks = (kWantItems + strips_total - 1) / strips_total;
-            const long long cols = ((long long)B->n_pad + want_chunks - 1) / want_chunks;
-            chunk_cols = (int)std::min<long long>(kChunkCols, std::max<long long>(2 * kStepRows, (cols + kStepRows - 1) / kStepRows * kStepRows));
-        }
+        const int chunk_cols = empty ? kChunkCols : chunk_cols_for(strips_total, B->n_pad);
         sp.chunk_cols = chunk_cols;
         sp.pad0 = 0;
         sp.nchunks = empty ? 0 : (B->n_pad + chunk_cols - 1) / chunk_cols;
@@ -386,8 +405,23 @@ extern "C" vsm_ctx* vsm_create(int device)
         fail(nullptr, VSM_ENODEV, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
         return nullptr;
     }
+    // this device's copy of the scratch array of vsm_match_pair_noalloc (the device is current here)
+    unsigned char* scratch_dev = nullptr;
+    if (device < kMaxDevices) {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        if (!g_scratch_ptr[device]) {
+            void* ptr = nullptr;
+            if ((e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch))) != hipSuccess || !ptr) {
+                fail(nullptr, VSM_ENODEV, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e));
+                return nullptr;
+            }
+            g_scratch_ptr[device] = ptr;
+        }
+        scratch_dev = static_cast<unsigned char*>(g_scratch_ptr[device]);
+    }
     vsm_ctx* c = new vsm_ctx();
     c->device = device;
+    c->noalloc_scratch = scratch_dev;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->slots[0].ev0)) != hipSuccess || (e = hipEventCreate(&c->slots[0].ev1)) != hipSuccess ||
         (e = hipEventCreate(&c->slots[0].ev2)) != hipSuccess || (e = hipEventCreate(&c->slots[0].ev3)) != hipSuccess ||
@@ -1318,6 +1352,82 @@ extern "C" int vsm_match_pair(vsm_ctx* c, int set0, int set1, const vsm_params* 
     }
     if (nm > cap) return fail(c, VSM_ECAP, "%d matches do not fit a buffer of %d", nm, cap);
     return nm;
+}
+
+// One u8 pair through the same kernels as vsm_match_pair, with every intermediate in the per-device
+// static scratch array and the results written straight into the caller's device buffers.  Calls no
+// hipMalloc / hipFree / allocating routine: the pair record travels as a kernel argument and the work
+// items are written by a kernel.
+extern "C" int vsm_match_pair_noalloc(vsm_ctx* c, int set0, int set1, const vsm_params* p,
+                                      int32_t* idx0_dev, int32_t* idx1_dev, int32_t* count_dev, int cap)
+{
+    if (!c) return VSM_EINVAL;
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    const DescSet* A = get_set(c, set0);
+    const DescSet* B = get_set(c, set1);
+    if (!A || !B) return fail(c, VSM_EINVAL, "unknown set id (%d, %d)", set0, set1);
+    if (A->kind != SET_U8 || B->kind != SET_U8)
+        return fail(c, VSM_EUNSUPPORTED, "vsm_match_pair_noalloc takes u8 (SIFT) sets only");
+    if (!idx0_dev || !idx1_dev || !count_dev) return fail(c, VSM_EINVAL, "idx0_dev, idx1_dev and count_dev must be device buffers");
+    if (A->n > kNoAllocMaxRows || B->n > kNoAllocMaxRows)
+        return fail(c, VSM_ECAP, "vsm_match_pair_noalloc takes sets of at most %d rows (got %d and %d): its scratch is a fixed "
+                                 "%zu-byte array", kNoAllocMaxRows, A->n, B->n, kNoAllocScratchBytes);
+    if (cap < A->n) return fail(c, VSM_ECAP, "idx0_dev / idx1_dev must hold %d entries (one per image-0 row), cap is %d", A->n, cap);
+    if (!c->noalloc_scratch) return fail(c, VSM_EUNSUPPORTED, "no scratch array on device %d", c->device);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (A->n == 0 || B->n == 0) {
+        HIPCHK(c, hipMemsetAsync(count_dev, 0, sizeof(int32_t), c->stream));
+        return VSM_OK;
+    }
+    SiftPair sp{};
+    sp.fragA = static_cast<const int8_t*>(A->frag);
+    sp.nrmA = static_cast<const int32_t*>(A->nrm);
+    sp.fragB = static_cast<const int8_t*>(B->frag);
+    sp.nrmB = static_cast<const int32_t*>(B->nrm);
+    sp.nA = A->n; sp.nB = B->n; sp.nA_pad = A->n_pad; sp.nB_pad = B->n_pad;
+    sp.nstrips = A->n_pad / kStripRows;
+    sp.chunk_cols = chunk_cols_for(sp.nstrips, B->n_pad);
+    sp.nchunks = (B->n_pad + sp.chunk_cols - 1) / sp.chunk_cols;
+    const int nitems = sp.nstrips * sp.nchunks;
+    const int nvitems = p->mutual ? (A->n + kVerifyBlock - 1) / kVerifyBlock : 0;
+    const size_t rows = (size_t)sp.nchunks * sp.nA_pad, out0 = (size_t)A->n;
+    // carve the scratch array (every part 256-byte aligned)
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return c->noalloc_scratch + at;
+    };
+    SiftPair* d_pair = reinterpret_cast<SiftPair*>(carve(sizeof(SiftPair)));
+    SiftItem* d_items = reinterpret_cast<SiftItem*>(carve(sizeof(SiftItem) * (size_t)(nitems + nvitems) + 64));
+    int32_t* rr1 = reinterpret_cast<int32_t*>(carve(rows * 4));
+    int32_t* rrj = reinterpret_cast<int32_t*>(carve(rows * 4));
+    int32_t* rr2 = reinterpret_cast<int32_t*>(carve(rows * 4));
+    SiftCandidates cand{};
+    cand.vbest = reinterpret_cast<unsigned long long*>(carve(out0 * 8));
+    cand.i0 = reinterpret_cast<int32_t*>(carve(out0 * 4));
+    cand.j1 = reinterpret_cast<int32_t*>(carve(out0 * 4));
+    cand.d1 = reinterpret_cast<int32_t*>(carve(out0 * 4));
+    cand.count = reinterpret_cast<int32_t*>(carve(sizeof(int32_t)));
+    if (off > kNoAllocScratchBytes)
+        return fail(c, VSM_ECAP, "this pair needs %zu bytes of scratch, the fixed array holds %zu", off, kNoAllocScratchBytes);
+    // Everything a kernel of this call reads from the scratch array is written earlier in the same call
+    // (pair record and items by the plan kernel, partial results by the query pass for every padded row,
+    // candidate records and their count by the select pass, the verify item list by its plan kernel), so
+    // the contents an earlier call left behind are never read and nothing needs clearing.
+    launch_sift_plan_single(sp, d_pair, d_items, c->stream);
+    launch_sift_query(d_pair, d_items, nitems, rr1, rrj, rr2, c->stream);
+    SiftOutputs out{};
+    out.slot_i0 = idx0_dev;
+    out.slot_i1 = idx1_dev;
+    out.counts = count_dev;
+    launch_sift_select(d_pair, 1, rr1, rrj, rr2, make_rule(p), cand, out, c->stream);
+    if (nvitems)
+        launch_sift_verify(d_pair, 1, d_items + nitems, nvitems, reinterpret_cast<int*>(d_items + nitems + nvitems), cand, c->stream);
+    launch_sift_confirm(d_pair, 1, cand, nvitems ? 1 : 0, out, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return VSM_OK;
 }
 
 extern "C" int vsm_match_pair_dense(vsm_ctx* c, int set0, int set1, const vsm_params* p, int metric,

@@ -152,6 +152,9 @@ void launch_merge_top2(const int32_t* packed, const int64_t* base, int nslices, 
 
 void launch_sift_transform(const uint8_t* des, int n, int n_pad, int8_t* frag, int32_t* nrm8c,
                            hipStream_t s);
+// one-pair submission planned on the device: *pair_out = sp (row_off = out0_off = out1_off = 0), items =
+// every (strip, chunk) of it in strip-major order
+void launch_sift_plan_single(const SiftPair& sp, SiftPair* pair_out, SiftItem* items, hipStream_t s);
 // query-side pass: per (chunk, query row) best train row, its distance, runner-up distance
 void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
                        int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, hipStream_t s);
