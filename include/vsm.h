@@ -92,6 +92,17 @@ enum { VSM_F32_FAST_EXACT = 0, VSM_F32_MFMA_F32 = 1 };
 int vsm_set_f32_mode(vsm_ctx* ctx, int mode);
 /* Which of the two ran in the last float search on this context (-1: none yet). */
 int vsm_last_f32_path(const vsm_ctx* ctx);
+/* How u8 (SIFT) sets are searched.  Both forms return the same bits (exact integer distances, lowest
+ * index on ties).
+ *   VSM_U8_AUTO (default): submissions with a ratio test run the tile-minimum query pass (the matrix
+ *     cores produce half-distances directly, each lane keeps the minimum per 32-row tile) and settle row,
+ *     exact distance and tests for the few candidates afterwards; everything else (no ratio test, raw
+ *     2-NN) runs the packed form.
+ *   VSM_U8_PACKED: the packed form only (value and row in one key for every distance). */
+enum { VSM_U8_AUTO = 0, VSM_U8_PACKED = 1 };
+int vsm_set_u8_mode(vsm_ctx* ctx, int mode);
+/* Which query pass the last u8 submission ran: 0 = tile-minimum, 1 = packed (-1: none yet). */
+int vsm_last_u8_path(const vsm_ctx* ctx);
 int vsm_release_set(vsm_ctx* ctx, int set);
 int vsm_set_count(const vsm_ctx* ctx, int set);
 

@@ -9,6 +9,16 @@ from visual_slam_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=[0, 1], ids=["tilemin", "packed"])
+def u8_mode(matcher, request):
+    """Every test runs twice: with the tile-minimum query pass for ratio-test submissions (default), and
+    with the packed form only.  Same bits are demanded of both."""
+    matcher.set_u8_mode(request.param)
+    yield request.param
+    matcher.set_u8_mode(0)
+
+
 SIZES = [(1, 1), (1, 5), (5, 1), (2, 2), (37, 91), (256, 256), (257, 255), (300, 700), (777, 2048), (1000, 513)]
 
 
@@ -220,3 +230,97 @@ def test_submit_collect_keeps_order(matcher):
     for a, b in ids:
         matcher.release(a)
         matcher.release(b)
+
+
+def test_tile_minimum_path_is_the_one_that_runs(matcher, u8_mode):
+    a, b = synth.sift_pair(600, 900, seed=17)
+    s0, s1 = matcher.upload_u8(a), matcher.upload_u8(b)
+    try:
+        matcher.match_pair(s0, s1, ratio=0.8, mutual=True)
+        assert matcher.last_u8_path() == u8_mode          # 0: tile-minimum, 1: packed
+        matcher.match_pair(s0, s1, ratio=None, mutual=True)
+        assert matcher.last_u8_path() == 1                # no ratio test: packed form in either mode
+        matcher.knn2(s0, s1)
+        assert matcher.last_u8_path() == 1
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)
+
+
+def test_undecidable_candidates_are_rescanned(matcher):
+    """Rows the one-tile resolve cannot settle: the nearest distance tied between rows of different tiles
+    and of the two lane halves of one tile, runner-ups whose parity bit decides the ratio test, a runner-up
+    inside the winner's 16-row group, every ratio from loose to strict."""
+    rng = np.random.default_rng(18)
+    b = synth.sift_like(3000, rng)
+    a = synth.sift_like(400, rng)
+    for k in range(100):                      # exact copies: d1 = 0, tied winners far apart and adjacent
+        a[k] = b[7 * k]
+    b[2000:2050] = b[0:350:7]                 # second copy in a later tile: tie on the minimum across tiles
+    b[4:8] = b[0:4]                           # ... and across the lane halves of tile 0 (rows r and r + 4)
+    b[2900] = b[0]
+    for k in range(100, 200):                 # near copies with a runner-up one unit apart in one component
+        src = b[9 * k % 3000].copy()
+        a[k] = src
+        t = src.copy()
+        t[k % 128] = min(int(t[k % 128]) + 1, 255) if t[k % 128] < 255 else 254
+        b[(9 * k % 3000) + 1] = t             # same tile, usually the same 16-row group or the other half
+    for ratio in ((4, 5), (99, 100), (1, 2), (1, 100), (1, 1)):
+        s0, s1 = matcher.upload_u8(a), matcher.upload_u8(b)
+        try:
+            for mutual in (True, False):
+                g0, g1, gd = matcher.match_pair(s0, s1, ratio=ratio[0] / ratio[1], mutual=mutual, return_dist=True)
+                o0, o1, od = orc.match_u8(a, b, orc.params(ratio, mutual))
+                np.testing.assert_array_equal(g0, o0)
+                np.testing.assert_array_equal(g1, o1)
+                np.testing.assert_array_equal(gd, od)
+        finally:
+            matcher.release(s0)
+            matcher.release(s1)
+
+
+def test_parity_of_the_runner_up_decides(matcher):
+    """d1 * den^2 < num^2 * d2 with d2 straddling the boundary: rows built so that the true runner-up
+    distance is 2 k or 2 k + 1 around the value where the test flips."""
+    a = np.zeros((64, 128), np.uint8)
+    b = np.zeros((64 * 40, 128), np.uint8) + 200      # far filler
+    want_pairs = 0
+    for i in range(64):
+        a[i, :] = 10
+        a[i, i] = 60 + i                               # every query row distinct
+        near = a[i].copy()
+        near[(i + 1) % 128] += 2                       # d1 = 4
+        b[40 * i + 3] = near
+        run = a[i].copy()
+        run[(i + 2) % 128] += 2                        # 4
+        run[(i + 3) % 128] += 1 + (i & 1)              # + 1 or + 4: d2 = 5 or 8 ...
+        run[(i + 5) % 128] += (i >> 1) & 1             # ... + 0 or 1
+        b[40 * i + 3 + 32] = run                       # another tile
+    for ratio in ((4, 5), (9, 10), (8, 9), (2, 3), (89, 100)):
+        s0, s1 = matcher.upload_u8(a), matcher.upload_u8(b)
+        try:
+            g0, g1, gd = matcher.match_pair(s0, s1, ratio=ratio[0] / ratio[1], mutual=False, return_dist=True)
+            o0, o1, od = orc.match_u8(a, b, orc.params(ratio, False))
+            np.testing.assert_array_equal(g0, o0)
+            np.testing.assert_array_equal(g1, o1)
+            np.testing.assert_array_equal(gd, od)
+            want_pairs += len(o0)
+        finally:
+            matcher.release(s0)
+            matcher.release(s1)
+    assert want_pairs > 0
+
+
+def test_distance_cap_with_ratio(matcher):
+    a, b = synth.sift_pair(900, 1200, seed=19)
+    s0, s1 = matcher.upload_u8(a), matcher.upload_u8(b)
+    try:
+        for cap in (0, 1500, 20000, 10**9):
+            g0, g1, gd = matcher.match_pair(s0, s1, ratio=0.8, mutual=True, max_dist_sq=cap, return_dist=True)
+            o0, o1, od = orc.match_u8(a, b, orc.params((4, 5), True, max_dist_sq=cap))
+            np.testing.assert_array_equal(g0, o0)
+            np.testing.assert_array_equal(g1, o1)
+            np.testing.assert_array_equal(gd, od)
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)

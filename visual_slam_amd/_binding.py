@@ -10,6 +10,8 @@ LAYOUT_ROWS, LAYOUT_DIM_MAJOR = 0, 1
 NO_SECOND = 2**31 - 1
 F32_FAST_EXACT = 0
 F32_MFMA_F32 = 1
+U8_AUTO = 0
+U8_PACKED = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -55,6 +57,8 @@ SIGNATURES = {
     "vsm_set_scratch_budget": (C.c_int, [C.c_void_p, C.c_longlong]),
     "vsm_set_f32_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "vsm_last_f32_path": (C.c_int, [C.c_void_p]),
+    "vsm_set_u8_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "vsm_last_u8_path": (C.c_int, [C.c_void_p]),
     "vsm_release_set": (C.c_int, [C.c_void_p, C.c_int]),
     "vsm_set_count": (C.c_int, [C.c_void_p, C.c_int]),
     "vsm_match_pair": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_int,
@@ -417,6 +421,13 @@ class Matcher:
     def set_f32_mode(self, mode):
         """0 = bf16 coarse pass + exact re-rank (default), 1 = f32 matrix cores only; same results."""
         self._check(self._l.vsm_set_f32_mode(self._h, int(mode)))
+
+    def set_u8_mode(self, mode):
+        """0 = tile-minimum query pass for ratio-test submissions (default), 1 = packed form only; same results."""
+        self._check(self._l.vsm_set_u8_mode(self._h, int(mode)))
+
+    def last_u8_path(self):
+        return int(self._l.vsm_last_u8_path(self._h))
 
     def last_f32_path(self):
         return int(self._l.vsm_last_f32_path(self._h))

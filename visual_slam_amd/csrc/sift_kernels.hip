@@ -27,6 +27,8 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // u8 rows -> fragment-major int8 + shifted norms
 // ---------------------------------------------------------------------------------
 // One thread per 16-byte chunk of a row (8 threads per row, 8 rows per wave).
+// Besides nrm8c the kernel writes, at nrm8c[n_pad + row], the constant the tile-minimum query pass starts
+// its accumulators from: floor(nrm / 2) + (sum of the row's int8 values), kYPad for padding rows.
 __global__ void sift_transform_kernel(const uint8_t* __restrict__ des, int n, int n_pad,
                                       int8_t* __restrict__ frag, int32_t* __restrict__ nrm8c)
 {
@@ -37,7 +39,7 @@ __global__ void sift_transform_kernel(const uint8_t* __restrict__ des, int n, in
     uint4 v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
     if (row < n) v = *reinterpret_cast<const uint4*>(des + (size_t)row * kDescDim + chunk * 16);
     v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
-    int sum = 0;
+    int sum = 0, lin = 0;
     const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -45,6 +47,7 @@ __global__ void sift_transform_kernel(const uint8_t* __restrict__ des, int n, in
         for (int b = 0; b < 4; ++b) {
             int e = (int)(int8_t)((w[i] >> (8 * b)) & 0xff);
             sum += e * e;
+            lin += e;
         }
     }
     // bytes k = 16*chunk .. +15 : k-step s = chunk >> 1, half h = chunk & 1
@@ -53,7 +56,13 @@ __global__ void sift_transform_kernel(const uint8_t* __restrict__ des, int n, in
     sum += __shfl_xor(sum, 1);
     sum += __shfl_xor(sum, 2);
     sum += __shfl_xor(sum, 4);
-    if (chunk == 0) nrm8c[row] = ((row < n) ? (sum << 8) : kNormPad) | (row & 255);
+    lin += __shfl_xor(lin, 1);
+    lin += __shfl_xor(lin, 2);
+    lin += __shfl_xor(lin, 4);
+    if (chunk == 0) {
+        nrm8c[row] = ((row < n) ? (sum << 8) : kNormPad) | (row & 255);
+        nrm8c[n_pad + row] = row < n ? (sum >> 1) + lin : kYPad;
+    }
 }
 
 void launch_sift_transform(const uint8_t* des, int n, int n_pad, int8_t* frag, int32_t* nrm8c,
@@ -306,6 +315,370 @@ void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
                        pairs, items, rr_d1, rr_j1, rr_d2, -512);
 }
 
+// ---- 1b. query pass, tile-minimum form ---------------------------------------------------
+// The form above spends 2.25 vector instructions per distance (scale + pack, running two smallest), which
+// makes the vector issue port, not the matrix pipe, its limit.  This form spends 0.75:
+//   * the accumulators start from the train rows' constants cq and the query operand is ~p, so the MFMA
+//     result is the half-distance y = floor(nrm(q) / 2) - p.q itself (no per-element arithmetic);
+//   * per lane and 32-row tile only the minimum m of the 16 values is taken (eight v_min3), then
+//     k2 = med3(k1, k2, m), tile = m < k1 ? this tile : tile, k1 = min(k1, m).
+// A lane therefore knows the smallest y of its query row (k1), the first tile that holds it, and the
+// second smallest of the per-(tile, lane half) minima (k2): an upper bound of the runner-up that misses only
+// rows of the winner's own 16-row group.  What this leaves open -- which row of the tile, the parity bit
+// that y drops, a runner-up inside the winner's group -- is settled for the candidates only, from that one
+// tile (sift_resolve_kernel), and in the rare undecidable case by a scan of the whole train set
+// (sift_rescan_kernel).  Results are bit-identical to the packed form's.
+__global__ __launch_bounds__(kQueryWaves * 64, 2)
+void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ items,
+                            int32_t* __restrict__ rr_y1, int32_t* __restrict__ rr_tile,
+                            int32_t* __restrict__ rr_k2)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SiftItem it = items[xcd_contiguous_item(blockIdx.x, gridDim.x)];
+    const SiftPair pw = pairs[it.pair];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane5 = lane & 31;
+    const int half = lane >> 5;
+
+    const int c0 = it.chunk * pw.chunk_cols;
+    const int ncols = min(pw.chunk_cols, pw.nB_pad - c0);
+    const int nsteps = ncols / kStepRows;
+
+    // persistent operand: this wave's query rows, complemented (~p = -p - 1; cq holds the + sum(q))
+    const int qtile = (it.strip * (kStripRows / 32)) + wave * kQueryRB;
+    v4i pf[kQueryRB][4];
+#pragma unroll
+    for (int rb = 0; rb < kQueryRB; ++rb) {
+        const int8_t* src = pw.fragA + (size_t)(qtile + rb) * kTileBytes + lane * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pf[rb][s] = ~*reinterpret_cast<const v4i*>(src + s * 1024);
+    }
+
+    const int8_t* Bsrc = pw.fragB + (size_t)(c0 >> 5) * kTileBytes + wave * (kLdsTile / kQueryWaves) + lane * 16;
+    const int32_t* Csrc = pw.nrmB + pw.nB_pad + c0 + (wave & 3) * 64 + lane;
+
+    int k1[kQueryRB], k2[kQueryRB], kt[kQueryRB];
+#pragma unroll
+    for (int rb = 0; rb < kQueryRB; ++rb) { k1[rb] = kYPad; k2[rb] = kYPad; kt[rb] = 0; }
+
+    stage_step<kQueryWaves>(smem, 0, Bsrc, Csrc, wave);
+    __syncthreads();
+
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nsteps)
+            stage_step<kQueryWaves>(smem, cur ^ 1, Bsrc + (size_t)(st + 1) * kLdsTile, Csrc + (st + 1) * kStepRows, wave);
+        const char* Bt = smem + cur * kLdsTile + lane * 16;
+        const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm);
+        const int tile0 = (c0 >> 5) + st * kTilesPerStep;
+#pragma unroll
+        for (int t = 0; t < kTilesPerStep; ++t) {
+            const char* tile = Bt + t * 4096;
+            const v4i b0 = *reinterpret_cast<const v4i*>(tile);
+            const v4i b1 = *reinterpret_cast<const v4i*>(tile + 1024);
+            const v4i b2 = *reinterpret_cast<const v4i*>(tile + 2048);
+            const v4i b3 = *reinterpret_cast<const v4i*>(tile + 3072);
+            int c[16];
+            tile_consts(nl + t * 32, half, c);
+            v16i cv;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cv[e] = c[e];
+            v16i acc[kQueryRB];
+#pragma unroll
+            for (int rb = 0; rb < kQueryRB; ++rb) {
+                v16i z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b0, pf[rb][0], cv, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b1, pf[rb][1], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b2, pf[rb][2], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b3, pf[rb][3], z, 0, 0, 0);
+                acc[rb] = z;
+            }
+#pragma unroll
+            for (int rb = 0; rb < kQueryRB; ++rb) {
+                // plain min() on the accumulator registers (the compiler folds pairs into v_min3_i32): what
+                // reads an MFMA result must be visible to the compiler, which places the wait states the
+                // hardware needs between the matrix pipe's write and a vector read; inline assembly is not
+                int m = min(min(acc[rb][0], acc[rb][1]), acc[rb][2]);
+#pragma unroll
+                for (int e = 0; e < 6; ++e) m = min(min(m, acc[rb][3 + 2 * e]), acc[rb][4 + 2 * e]);
+                m = min(m, acc[rb][15]);
+                k2[rb] = med3i(k1[rb], k2[rb], m);           // k1 <= k2: the runner-up of {k1, k2, m}
+                kt[rb] = m < k1[rb] ? tile0 + t : kt[rb];    // strict: the first tile that holds the minimum
+                k1[rb] = min(k1[rb], m);
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int rb = 0; rb < kQueryRB; ++rb) {
+        // lanes l and l + 32 saw disjoint 16-row groups of every tile for the same query row
+        const int o1 = __shfl_xor(k1[rb], 32);
+        const int o2 = __shfl_xor(k2[rb], 32);
+        const int ot = __shfl_xor(kt[rb], 32);
+        const bool other = o1 < k1[rb] || (o1 == k1[rb] && ot < kt[rb]);
+        const int y1 = min(k1[rb], o1);
+        const int tl = other ? ot : kt[rb];
+        const int y2 = min(max(k1[rb], o1), min(k2[rb], o2));
+        if (half == 0) {
+            const int grow = (qtile + rb) * 32 + lane5;
+            const size_t o = pw.row_off + (size_t)it.chunk * pw.nA_pad + grow;
+            rr_y1[o] = y1;
+            rr_tile[o] = tl;
+            rr_k2[o] = y2;
+        }
+    }
+}
+
+void launch_sift_query_tile(const SiftPair* pairs, const SiftItem* items, int nitems,
+                            int32_t* rr_y1, int32_t* rr_tile, int32_t* rr_k2, hipStream_t s)
+{
+    static DeviceFlags attr_set;   // the attribute is per device
+    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(sift_query_tile_kernel), kLdsStream);
+    hipLaunchKernelGGL(sift_query_tile_kernel, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
+                       pairs, items, rr_y1, rr_tile, rr_k2);
+}
+
+// ---- 2b. select, tile-minimum form --------------------------------------------------------
+// Chunk merge and OPTIMISTIC tests: the nearest row's exact distance is 2 y1 + (0 or 1) + nrm(a), the
+// runner-up's is at most 2 k2 + 1 + nrm(a), so a row that fails with d1 at its lowest and d2 at its highest
+// fails for certain; everything else becomes a candidate for the resolve pass.
+__global__ __launch_bounds__(1024)
+void sift_select_tile_kernel(const SiftPair* __restrict__ pairs,
+                             const int32_t* __restrict__ rr_y1, const int32_t* __restrict__ rr_tile,
+                             const int32_t* __restrict__ rr_k2, MatchRule rule, SiftCandidates cand)
+{
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const SiftPair pw = pairs[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid == 0) base_s = 0;
+    if (blockIdx.x == 0 && tid == 0) *cand.rescan_count = 0;
+    __syncthreads();
+
+    constexpr int R = 8;
+    for (int i0 = 0; i0 < pw.nA; i0 += 1024 * R) {
+        const int ib = i0 + tid * R;
+        int tl[R], y1[R], y2[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { tl[r] = 0; y1[r] = kYPad; y2[r] = kYPad; }
+        if (ib < pw.nA) {
+            for (int c = 0; c < pw.nchunks; ++c) {
+                const size_t o = pw.row_off + (size_t)c * pw.nA_pad + ib;
+                int e1[R], et[R], e2[R];
+#pragma unroll
+                for (int q = 0; q < R / 4; ++q) {
+                    const int4 v1 = *reinterpret_cast<const int4*>(rr_y1 + o + 4 * q);
+                    const int4 vt = *reinterpret_cast<const int4*>(rr_tile + o + 4 * q);
+                    const int4 v2 = *reinterpret_cast<const int4*>(rr_k2 + o + 4 * q);
+                    e1[4 * q] = v1.x; e1[4 * q + 1] = v1.y; e1[4 * q + 2] = v1.z; e1[4 * q + 3] = v1.w;
+                    et[4 * q] = vt.x; et[4 * q + 1] = vt.y; et[4 * q + 2] = vt.z; et[4 * q + 3] = vt.w;
+                    e2[4 * q] = v2.x; e2[4 * q + 1] = v2.y; e2[4 * q + 2] = v2.z; e2[4 * q + 3] = v2.w;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (e1[r] < y1[r]) {       // a tie between chunks leaves y2 == y1: the resolve pass rescans
+                        y2[r] = min(y1[r], e2[r]);
+                        y1[r] = e1[r];
+                        tl[r] = et[r];
+                    } else {
+                        y2[r] = min(y2[r], e1[r]);
+                    }
+                }
+            }
+        }
+        unsigned okbits = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = ib + r;
+            if (i >= pw.nA) continue;
+            bool ok = y1[r] < kYPad;
+            const long long na = pw.nrmA[i] >> 8;
+            const long long d1lo = 2ll * y1[r] + na;
+            if (ok && rule.max_dist >= 0 && d1lo > rule.max_dist) ok = false;
+            if (ok && rule.num2 > 0 && y2[r] < kYPad) {
+                const long long d2hi = 2ll * y2[r] + 1 + na;
+                if (!(d1lo * rule.den2 < d2hi * rule.num2)) ok = false;
+            }
+            okbits |= (ok ? 1u : 0u) << r;
+        }
+        int slot = block_compact_range(__popc(okbits), wsum, &base_s);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if ((okbits >> r) & 1u) {
+                const size_t o = pw.out0_off + slot++;
+                cand.i0[o] = ib + r;
+                cand.j1[o] = tl[r];
+                cand.d1[o] = y1[r];
+                cand.aux[o] = y2[r];
+                cand.vbest[o] = ~0ull;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) cand.count[blockIdx.x] = base_s;
+}
+
+void launch_sift_select_tile(const SiftPair* pairs, int npairs, const int32_t* rr_y1, const int32_t* rr_tile,
+                             const int32_t* rr_k2, MatchRule rule, SiftCandidates cand, hipStream_t s)
+{
+    hipLaunchKernelGGL(sift_select_tile_kernel, dim3(npairs), dim3(1024), 0, s,
+                       pairs, rr_y1, rr_tile, rr_k2, rule, cand);
+}
+
+// ---- 2c. resolve / rescan ------------------------------------------------------------------
+__device__ __forceinline__ int dot16(const v4i a, const v4i b, int acc)
+{
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc = __builtin_amdgcn_sdot4(a[w], b[w], acc, false);
+    return acc;
+}
+
+// nrm(q) - 2 p.q for row (lane & 31) of 32-row train tile `tile` (INT32_MAX for padding rows), the same
+// value in lanes l and l + 32.  qa: this lane's 16-byte pieces of the query row, one per k-step.
+__device__ __forceinline__ int tile_row_x(const SiftPair& pw, int tile, int lane, const v4i (&qa)[4])
+{
+    const int8_t* tb = pw.fragB + (size_t)tile * kTileBytes + lane * 16;
+    int dot = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dot = dot16(qa[s], *reinterpret_cast<const v4i*>(tb + s * 1024), dot);
+    dot += __shfl_xor(dot, 32);
+    const int row = tile * 32 + (lane & 31);
+    return row < pw.nB ? (pw.nrmB[row] >> 8) - 2 * dot : INT32_MAX;
+}
+
+__device__ __forceinline__ int wave_min32(int v)   // minimum over lanes 0..31, valid in all of them
+{
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
+    return v;
+}
+
+__device__ __forceinline__ bool ratio_ok(const MatchRule& rule, long long d1, long long d2)
+{
+    return rule.num2 <= 0 || d1 * rule.den2 < d2 * rule.num2;
+}
+
+// One wave per candidate: the 32 exact distances of its tile give the nearest row (lowest row among equal
+// distances), the exact d1 and the runner-up inside the tile; with the runner-up outside known up to its
+// parity bit the tests are decided unless that bit matters or the minimum is tied with another group.
+constexpr int kResolveWaves = 4;
+__global__ __launch_bounds__(kResolveWaves * 64)
+void sift_resolve_kernel(const SiftPair* __restrict__ pairs, int slices, MatchRule rule, SiftCandidates cand)
+{
+    const int item = xcd_contiguous_item(blockIdx.x, gridDim.x);
+    const int p = item / slices, sl = item % slices;
+    const SiftPair pw = pairs[p];
+    const int ncand = cand.count[p];
+    const int lane = threadIdx.x & 63, lane5 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int c = sl * kResolveWaves + wave; c < ncand; c += slices * kResolveWaves) {
+        const size_t o = pw.out0_off + c;
+        const int i = cand.i0[o], tl = cand.j1[o], y1 = cand.d1[o], y2 = cand.aux[o];
+        const int8_t* qsrc = pw.fragA + (size_t)(i >> 5) * kTileBytes + (half * 32 + (i & 31)) * 16;
+        v4i qa[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qa[s] = *reinterpret_cast<const v4i*>(qsrc + s * 1024);
+        const int x = tile_row_x(pw, tl, lane, qa);
+        // |x| < 2^23: value and row in one key
+        const int key = x == INT32_MAX ? INT32_MAX : x * 32 + lane5;
+        const int best = wave_min32(key);
+        const int r1 = best & 31, x1 = best >> 5;
+        const int key2 = wave_min32(lane5 == r1 ? INT32_MAX : key);
+        const long long na = pw.nrmA[i] >> 8;
+        const long long d1 = (long long)x1 + na;
+        bool amb = y2 == y1 || (x1 >> 1) != y1;   // minimum tied with another group: the nearest row may lie there
+        bool pass = false;
+        if (!amb) {
+            const bool has_in = key2 != INT32_MAX, has_out = y2 < kYPad;
+            bool pr = true;
+            if (has_in || has_out) {
+                const long long in_x = has_in ? (long long)(key2 >> 5) : INT64_MAX / 4;
+                const long long out_lo = has_out ? 2ll * y2 : INT64_MAX / 4;
+                const bool pa = ratio_ok(rule, d1, min(in_x, out_lo) + na);
+                const bool pb = ratio_ok(rule, d1, min(in_x, out_lo + 1) + na);
+                if (pa != pb) amb = true;   // the parity bit of the runner-up decides
+                pr = pa;
+            }
+            pass = pr && (rule.max_dist < 0 || d1 <= rule.max_dist);
+        }
+#ifdef VSM_DEBUG_RESOLVE
+        if (lane == 0) printf("resolve c=%d i=%d tl=%d y1=%d y2=%d x1=%d r1=%d key2=%d amb=%d pass=%d\n", c, i, tl, y1, y2, x1, r1, key2, (int)amb, (int)pass);
+#endif
+        if (lane == 0) {
+            if (amb) {
+                const int k = atomicAdd(cand.rescan_count, 1);
+                cand.rescan_list[k] = make_int2(p, c);
+                cand.j1[o] = -1;
+            } else {
+                cand.j1[o] = pass ? tl * 32 + r1 : -1;
+                cand.d1[o] = (int)d1;
+            }
+        }
+    }
+}
+
+// The candidates one tile could not settle: exact two nearest over the whole train set, one wave each.
+constexpr int kRescanGrid = 512;
+__global__ __launch_bounds__(kResolveWaves * 64)
+void sift_rescan_kernel(const SiftPair* __restrict__ pairs, MatchRule rule, SiftCandidates cand)
+{
+    const int total = *cand.rescan_count;
+    const int lane = threadIdx.x & 63, lane5 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int e = blockIdx.x * kResolveWaves + wave; e < total; e += gridDim.x * kResolveWaves) {
+        const int2 pc = cand.rescan_list[e];
+        const SiftPair pw = pairs[pc.x];
+        const size_t o = pw.out0_off + pc.y;
+        const int i = cand.i0[o];
+        const int8_t* qsrc = pw.fragA + (size_t)(i >> 5) * kTileBytes + (half * 32 + (i & 31)) * 16;
+        v4i qa[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qa[s] = *reinterpret_cast<const v4i*>(qsrc + s * 1024);
+        // per lane: rows lane5, lane5 + 32, ... in ascending order (strict compare keeps the lowest row)
+        int b1 = INT32_MAX, b1row = INT32_MAX, b2 = INT32_MAX;
+        const int ntiles = pw.nB_pad / 32;
+        for (int tl = 0; tl < ntiles; ++tl) {
+            const int x = tile_row_x(pw, tl, lane, qa);
+            if (x < b1) {
+                b2 = b1;
+                b1 = x;
+                b1row = tl * 32 + lane5;
+            } else {
+                b2 = min(b2, x);
+            }
+        }
+        // winner over lanes by (distance, row); runner-up = best of the other lanes' nearest and the winner lane's second
+        const int wx = wave_min32(b1);
+        const int wrow = wave_min32(b1 == wx ? b1row : INT32_MAX);
+        const int x2 = wave_min32(b1row == wrow ? b2 : b1);
+        const long long na = pw.nrmA[i] >> 8;
+        const long long d1 = (long long)wx + na;
+        bool pass = wx != INT32_MAX;
+        if (pass && x2 != INT32_MAX) pass = ratio_ok(rule, d1, (long long)x2 + na);
+        if (pass && rule.max_dist >= 0 && d1 > rule.max_dist) pass = false;
+#ifdef VSM_DEBUG_RESOLVE
+        if (lane == 0) printf("rescan e=%d i=%d wx=%d wrow=%d x2=%d pass=%d\n", e, i, wx, wrow, x2, (int)pass);
+#endif
+        if (lane == 0) {
+            cand.j1[o] = pass ? wrow : -1;
+            cand.d1[o] = (int)d1;
+        }
+    }
+}
+
+void launch_sift_resolve(const SiftPair* pairs, int npairs, int max_rows, MatchRule rule, SiftCandidates cand,
+                         hipStream_t s)
+{
+    if (npairs <= 0) return;
+    // enough waves per pair for its candidates (at most one per row), few enough blocks for short lists
+    const int slices = std::max(1, std::min(64, (max_rows + 511) / 512));
+    hipLaunchKernelGGL(sift_resolve_kernel, dim3(npairs * slices), dim3(kResolveWaves * 64), 0, s, pairs, slices, rule, cand);
+    hipLaunchKernelGGL(sift_rescan_kernel, dim3(kRescanGrid), dim3(kResolveWaves * 64), 0, s, pairs, rule, cand);
+}
+
 // ---- 3. verify pass -------------------------------------------------------------------
 // Persistent rows = the image-1 rows named by a block of 256 candidates (gathered from the
 // operand-order layout: kVerifyRB blocks of 32 per wave, sharing every streamed operand read);
@@ -345,7 +718,7 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
 #pragma unroll
     for (int rb = 0; rb < kVerifyRB; ++rb) {
         ci[rb] = cbase + (wave * kVerifyRB + rb) * 32 + lane5;
-        const int j = ci[rb] < ncand ? cand.j1[pw.out0_off + ci[rb]] : 0;
+        const int j = ci[rb] < ncand ? max(cand.j1[pw.out0_off + ci[rb]], 0) : 0;   // -1: rejected by the resolve pass
         const int8_t* src = pw.fragB + (size_t)(j >> 5) * kTileBytes + (half * 32 + (j & 31)) * 16;
 #pragma unroll
         for (int s = 0; s < 4; ++s) pf[rb][s] = *reinterpret_cast<const v4i*>(src + s * 1024);
@@ -590,7 +963,7 @@ void sift_confirm_kernel(const SiftPair* __restrict__ pairs, SiftCandidates cand
             i = cand.i0[o];
             j = cand.j1[o];
             d = cand.d1[o];
-            ok = !mutual || (int)(unsigned)(cand.vbest[o] & 0xffffffffull) == i;
+            ok = j >= 0 && (!mutual || (int)(unsigned)(cand.vbest[o] & 0xffffffffull) == i);
         }
         const int slot = block_compact_slot(ok, wsum, &base_s);
         if (ok) {

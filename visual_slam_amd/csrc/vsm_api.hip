@@ -108,6 +108,8 @@ struct vsm_ctx {
     DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_probs, d_geom, d_short;
     // float sets: 0 = bf16 coarse pass + exact re-rank (exact kernel when a survivor list overflows), 1 = exact kernel only
     int f32_mode = 0, last_f32_path = -1;
+    // u8 sets: 0 = the tile-minimum query pass for ratio-test submissions (packed form otherwise), 1 = packed form only
+    int u8_mode = 0, last_u8_path = -1;
     int* flag_dev = nullptr;   // survivor-overflow flag of the last coarse submission (inside d_probs)
     HostBuf h_small, h_probs, h_gather;
     // Two sets of per-submission staging and result buffers, so that vsm_match_pairs can queue
@@ -254,6 +256,7 @@ int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
 
 struct RunOpts {
     bool want_dense = false, want_knn = false, want_dist = false, want_pack = true;
+    bool packed_only = false;   // keep to the packed query pass whatever the rule
 };
 
 // Queues the whole u8 pipeline for one planned submission.
@@ -272,7 +275,12 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     HIPCHK(c, c->d_rr1.ensure(rows * 4));
     HIPCHK(c, c->d_rrj.ensure(rows * 4));
     HIPCHK(c, c->d_rr2.ensure(rows * 4));
-    HIPCHK(c, c->d_cand.ensure(out0 * 20 + sizeof(int32_t) * std::max(npairs, 1)));
+    // vbest (8) + i0, j1, d1, aux (4 each) + rescan list (8) per row, then per-pair counts and the rescan counter
+    HIPCHK(c, c->d_cand.ensure(out0 * 32 + sizeof(int32_t) * (std::max(npairs, 1) + 16)));
+    // The tile-minimum query pass leaves row and exact distances to a resolve pass over the candidates: it
+    // pays when the ratio test keeps the candidates few, and it does not produce the raw 2-NN outputs.
+    const bool tile_path = c->u8_mode == 0 && !o.packed_only && rule.num2 > 0 && !o.want_knn;
+    c->last_u8_path = nitems ? (tile_path ? 0 : 1) : c->last_u8_path;
     HIPCHK(c, c->d_slot0.ensure(out0 * 4));
     HIPCHK(c, c->d_slot1.ensure(out0 * 4));
     if (o.want_dist) HIPCHK(c, c->d_slotd.ensure(out0 * 4));
@@ -304,8 +312,12 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     c->R().ev_verify_valid = false;
     if (nitems) {
         if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
-        launch_sift_query(c->d_pairs.as<SiftPair>(), c->d_items.as<SiftItem>(), nitems,
-                          c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), c->stream);
+        if (tile_path)
+            launch_sift_query_tile(c->d_pairs.as<SiftPair>(), c->d_items.as<SiftItem>(), nitems,
+                                   c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), c->stream);
+        else
+            launch_sift_query(c->d_pairs.as<SiftPair>(), c->d_items.as<SiftItem>(), nitems,
+                              c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), c->stream);
         if (c->timing) {
             HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
             c->R().ev_valid = true;
@@ -317,7 +329,10 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
         cand.i0 = reinterpret_cast<int32_t*>(cand.vbest + out0);
         cand.j1 = cand.i0 + out0;
         cand.d1 = cand.j1 + out0;
-        cand.count = cand.d1 + out0;
+        cand.aux = cand.d1 + out0;
+        cand.rescan_list = reinterpret_cast<int2*>(cand.aux + out0);
+        cand.count = reinterpret_cast<int32_t*>(cand.rescan_list + out0);
+        cand.rescan_count = cand.count + std::max(npairs, 1);
         SiftOutputs out{};
         out.slot_i0 = c->d_slot0.as<int32_t>();
         out.slot_i1 = c->d_slot1.as<int32_t>();
@@ -332,8 +347,16 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
             out.knn_d1 = c->d_knn1.as<int32_t>();
             out.knn_d2 = c->d_knn2.as<int32_t>();
         }
-        launch_sift_select(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(),
-                           c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, out, c->stream);
+        if (tile_path) {
+            int max_rows = 0;
+            for (const SiftPair& sp : pl.pairs) max_rows = std::max(max_rows, sp.nA);
+            launch_sift_select_tile(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(),
+                                    c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, c->stream);
+            launch_sift_resolve(c->d_pairs.as<SiftPair>(), npairs, max_rows, rule, cand, c->stream);
+        } else {
+            launch_sift_select(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(),
+                               c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, out, c->stream);
+        }
         if (nvitems) {
             if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev2, c->stream));
             launch_sift_verify(c->d_pairs.as<SiftPair>(), npairs, c->d_items.as<SiftItem>() + nitems, nvitems,
@@ -533,7 +556,8 @@ static int upload_u8_common(vsm_ctx* c, const void* src, int n, bool src_on_devi
     s.dim = kDescDim;
     if (s.n_pad > 0) {
         HIPCHK(c, hipMalloc(&s.frag, (size_t)s.n_pad * kDescDim));
-        hipError_t e = hipMalloc(&s.nrm, (size_t)s.n_pad * sizeof(int32_t));
+        // nrm8c[n_pad] followed by the half-distance constants cq[n_pad] of the tile-minimum query pass
+        hipError_t e = hipMalloc(&s.nrm, (size_t)s.n_pad * 2 * sizeof(int32_t));
         if (e != hipSuccess) {
             (void)hipFree(s.frag);
             return fail(c, VSM_ENOMEM, "hipMalloc(norms): %s", hipGetErrorString(e));
@@ -632,6 +656,16 @@ extern "C" int vsm_upload_f32_device(vsm_ctx* c, const void* des_dev, int n, int
 {
     return upload_f32_common(c, des_dev, n, dim, layout, true);
 }
+
+extern "C" int vsm_set_u8_mode(vsm_ctx* c, int mode)
+{
+    if (!c) return VSM_EINVAL;
+    if (mode != VSM_U8_AUTO && mode != VSM_U8_PACKED) return fail(c, VSM_EINVAL, "unknown u8 mode %d", mode);
+    c->u8_mode = mode;
+    return VSM_OK;
+}
+
+extern "C" int vsm_last_u8_path(const vsm_ctx* c) { return c ? c->last_u8_path : VSM_EINVAL; }
 
 extern "C" int vsm_release_set(vsm_ctx* c, int set)
 {

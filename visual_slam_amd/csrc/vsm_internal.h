@@ -30,6 +30,13 @@ constexpr int kStepRows = 256;        // streamed rows per main-loop step
 constexpr int kChunkCols = 8192;      // streamed rows per work item of the query-side pass, at most
 constexpr int32_t kNormPad = 0x7FFFFF00;
 constexpr int32_t kDistPad = 0x7FFFFF;  // (kNormPad >> 8): "no such neighbour"
+// Half-distance domain of the tile-minimum query pass: for a query row p and a train row q (both int8),
+//     y = floor(nrm(q) / 2) - dot(p, q),   nrm(q) - 2 dot(p, q) = 2 y + (nrm(q) & 1),
+// |y| < 2^22 for real rows; padding rows and "no such neighbour" are kYPad.
+// The int32 array of a u8 set holds nrm8c[n_pad] followed by these constants, cq[n_pad]:
+//     cq[row] = floor(nrm / 2) + (sum of the row's int8 values)
+// (the query operand enters the MFMA as ~p = -p - 1, so the accumulator that starts at cq ends at y).
+constexpr int32_t kYPad = 1 << 28;
 
 struct SiftPair {
     const int8_t* fragA;     // image 0 (queries)
@@ -66,6 +73,12 @@ struct SiftCandidates {
     // nearest image-0 row of column j1 as (distance with its sign bit flipped << 32 | row): set to all ones by the select pass,
     // lowered by the verify pass with an atomic minimum (lowest row among equal distances)
     unsigned long long* vbest;
+    // tile-minimum path only.  Between its select and resolve passes j1 holds the 32-row train tile of the
+    // nearest row, d1 its half-distance y1, aux the smallest half-distance outside that tile's lane group;
+    // the resolve pass replaces j1 by the row (-1: rejected) and d1 by the exact squared distance.
+    int32_t* aux;
+    int32_t* rescan_count;   // candidates the resolve pass could not settle from one tile ...
+    int2* rescan_list;       // ... as (pair, candidate); the rescan pass searches the whole train set for them
 };
 
 struct SiftOutputs {
@@ -158,6 +171,16 @@ void launch_sift_plan_single(const SiftPair& sp, SiftPair* pair_out, SiftItem* i
 // query-side pass: per (chunk, query row) best train row, its distance, runner-up distance
 void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
                        int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, hipStream_t s);
+// Tile-minimum form of the query pass and its follow-ups (ratio-test submissions): per (chunk, query row)
+// the smallest half-distance y1, the 32-row train tile that holds it, and the smallest half-distance outside
+// that tile's lane group; select with optimistic tests (a superset of the final candidates); resolve from the
+// one tile (row, exact distance, exact tests), rescan of the few rows one tile cannot settle.
+void launch_sift_query_tile(const SiftPair* pairs, const SiftItem* items, int nitems,
+                            int32_t* rr_y1, int32_t* rr_tile, int32_t* rr_k2, hipStream_t s);
+void launch_sift_select_tile(const SiftPair* pairs, int npairs, const int32_t* rr_y1, const int32_t* rr_tile,
+                             const int32_t* rr_k2, MatchRule rule, SiftCandidates cand, hipStream_t s);
+void launch_sift_resolve(const SiftPair* pairs, int npairs, int max_rows, MatchRule rule, SiftCandidates cand,
+                         hipStream_t s);
 // chunk merge + distance/ratio tests -> candidate lists (+ raw 2-NN outputs)
 void launch_sift_select(const SiftPair* pairs, int npairs, const int32_t* rr_d1, const int32_t* rr_j1,
                         const int32_t* rr_d2, MatchRule rule, SiftCandidates cand, SiftOutputs out,
