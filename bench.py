@@ -30,7 +30,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3    # f32-input MFMA (exact f32), = vector peak
 BF16_DENSE_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA
 
 
-def measured_traffic(kernel, summary="r01_traffic_sift_exhaustive.json"):
+def measured_traffic(kernel, summary="r02_traffic_sift_exhaustive.json"):
     """HBM bytes per launch of `kernel` from the committed hardware-counter passes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE over tools/traffic_probe.py or tools/db_query_probe.py at this workload's
     shape, folded by tools/pmc_summary.py); None when no such pass is in the tree."""
@@ -44,8 +44,8 @@ def measured_traffic(kernel, summary="r01_traffic_sift_exhaustive.json"):
 
 def measured_mfma_busy(kernel):
     """Fraction of the elapsed SIMD cycles in which the matrix pipes were busy, from the committed counter
-    pass (profiles/r01_mfma_utilisation.txt, written by tools/refresh_profiles.sh); None when absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_mfma_utilisation.txt")
+    pass (profiles/r02_mfma_utilisation.txt, written by tools/refresh_profiles.sh); None when absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_mfma_utilisation.txt")
     try:
         for line in open(path):
             if line.startswith(kernel + ":") and "SIMDs) = " in line:
@@ -338,16 +338,18 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
                      "frac": achieved / INT8_DENSE_PEAK_TOPS,
                      "frac_step": OPS_PER_EVAL_U8 * float(pps) * nfeat * nfeat / (dt / args.steps) / 1e12
                                   / INT8_DENSE_PEAK_TOPS,
-                     "traffic": measured_traffic("vsm::sift_query_kernel")
+                     "traffic": measured_traffic("vsm::sift_query_tile_kernel")
                      if (nimg, nfeat, launch_pairs) == (1000, 8192, 2048) else None,
-                     "mfma_busy_frac": measured_mfma_busy("vsm::sift_query_kernel")
+                     "mfma_busy_frac": measured_mfma_busy("vsm::sift_query_tile_kernel")
                      if (nimg, nfeat, launch_pairs) == (1000, 8192, 2048) else None,
-                     "mfma_busy_note": "matrix-pipe busy cycles / (elapsed cycles x SIMDs) from a separate counter pass "
-                                       "(profiles/r01_mfma_utilisation.txt); the chip clocks at about 1.85 GHz under this load",
-                     "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes "
-                                     "(profiles/r01_probe1000_pmc_*.csv; FETCH_SIZE doubled as gfx950 needs); "
-                                     "algorithmic operand bytes per launch: %d" % (launch_pairs * 2 * nfeat * 128),
-                     "kernel": "sift_query_kernel", "kernel_ms": kms,
+                     "mfma_busy_note": "matrix-pipe busy cycles / (elapsed cycles x SIMDs): a constant read from a committed "
+                                       "counter pass over the same submission shape (profiles/r02_mfma_utilisation.txt), "
+                                       "not a measurement of this run",
+                     "traffic_note": "HBM bytes per launch: a constant read from committed rocprofv3 --pmc passes over the same "
+                                     "submission shape (profiles/r02_probe1000_pmc_*.csv; FETCH_SIZE doubled as gfx950 needs), "
+                                     "not a measurement of this run; algorithmic operand bytes per launch: %d"
+                                     % (launch_pairs * 2 * nfeat * 128),
+                     "kernel": "sift_query_tile_kernel" if m.last_u8_path() == 0 else "sift_query_kernel", "kernel_ms": kms,
                      "verify_kernel_ms": float(np.mean(verify_ms)),
                      "note": "int8 ops: 256 per descriptor pair (128 MAC), one direction counted once"},
     }
@@ -542,7 +544,7 @@ def run_sift_large_pair(args, torch, dist, world, rank):
                    "parallelism": "replicas x%d" % world, "matches": int(tot)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                      "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": None,
-                     "kernel": "sift_query_kernel", "kernel_ms": kms},
+                     "kernel": "sift_query_tile_kernel" if m.last_u8_path() == 0 else "sift_query_kernel", "kernel_ms": kms},
     }
     if world == 1 and not args.no_cpu_baseline:
         sets = [arena[i, :8192].cpu().numpy() for i in range(2)]
@@ -744,7 +746,7 @@ def run_db_query(args, torch, dist, world, rank):
         "roofline": f32_roofline(m, OPS_PER_EVAL_F32 * float(nq) * (hi - lo), kms),
     }
     if world == 1 and m.last_f32_path() == 0:   # the counter passes were taken at this shape
-        out["roofline"]["traffic"] = measured_traffic("void vsm::bf16_coarse_kernel<256>", "r01_traffic_db_query.json")
+        out["roofline"]["traffic"] = measured_traffic("void vsm::bf16_coarse_kernel<256>", "r02_traffic_db_query.json")
     m.close()
     return out
 

@@ -32,10 +32,14 @@ def main():
     allp = vsm.generate_exhaustive_pairs(args.images)[: args.pairs]
     pr = np.asarray([[ids[a], ids[b]] for a, b in allp], np.int32)
     m.set_timing(True)
+    times = []
     for _ in range(args.reps):
         tot = m.match_pairs_device(pr, ratio=0.8, mutual=True)
         m.fetch_matches(len(pr), tot)
-    print("pairs %d matches %d query %.3f ms verify %.3f ms" % (len(pr), tot, m.last_kernel_ms(), m.last_verify_ms()))
+        times.append(m.last_kernel_ms())
+    times.sort()
+    print("pairs %d matches %d query min %.3f median %.3f max %.3f ms (%d launches) verify %.3f ms"
+          % (len(pr), tot, times[0], times[len(times) // 2], times[-1], len(times), m.last_verify_ms()))
     m.close()
 
 

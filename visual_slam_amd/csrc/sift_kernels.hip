@@ -364,6 +364,47 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
 #pragma unroll
     for (int rb = 0; rb < kQueryRB; ++rb) { k1[rb] = kYPad; k2[rb] = kYPad; kt[rb] = 0; }
 
+    // Software pipeline, written out because the compiler's own schedule reads a tile's operands from LDS
+    // right before its first MFMA and runs a tile's whole epilogue before the next tile's reads (3 % slower):
+    //   * the operands and constants of tile t + 1 are read while tile t multiplies;
+    //   * the epilogues of query blocks 2 and 3 trail by half a tile: they run between the MFMAs of blocks
+    //     0, 1 and of blocks 2, 3 of the NEXT tile, so every epilogue has MFMAs of other blocks in flight and
+    //     no accumulator set is live twice (four sets, as before).
+    // acc[2], acc[3] start as "nothing": their first (pending) epilogue changes no state.
+    static_assert(kQueryRB == 4, "the pipeline below is written for four query blocks per wave");
+    v16i acc[kQueryRB];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[2][e] = kYPad; acc[3][e] = kYPad; }
+    int pend_tile = 0;
+
+    auto load_tile = [&](const char* tile, const int* ctile, v4i (&b)[4], v16i& cv) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[s] = *reinterpret_cast<const v4i*>(tile + s * 1024);
+        int c[16];
+        tile_consts(ctile, half, c);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cv[e] = c[e];
+    };
+    auto mma = [&](int rb, const v4i (&b)[4], const v16i& cv) {
+        v16i z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[0], pf[rb][0], cv, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[1], pf[rb][1], z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[2], pf[rb][2], z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[3], pf[rb][3], z, 0, 0, 0);
+        acc[rb] = z;
+    };
+    auto epilogue = [&](int rb, int tileno) {
+        // plain min() on the accumulator registers (the compiler folds pairs into v_min3_i32): what reads
+        // an MFMA result must be visible to the compiler, which places the wait states the hardware needs
+        // between the matrix pipe's write and a vector read; inline assembly is not
+        int m = min(min(acc[rb][0], acc[rb][1]), acc[rb][2]);
+#pragma unroll
+        for (int e = 0; e < 6; ++e) m = min(min(m, acc[rb][3 + 2 * e]), acc[rb][4 + 2 * e]);
+        m = min(m, acc[rb][15]);
+        k2[rb] = med3i(k1[rb], k2[rb], m);          // k1 <= k2: the runner-up of {k1, k2, m}
+        kt[rb] = m < k1[rb] ? tileno : kt[rb];      // strict: the first tile that holds the minimum
+        k1[rb] = min(k1[rb], m);
+    };
+
     stage_step<kQueryWaves>(smem, 0, Bsrc, Csrc, wave);
     __syncthreads();
 
@@ -374,43 +415,42 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
         const char* Bt = smem + cur * kLdsTile + lane * 16;
         const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm);
         const int tile0 = (c0 >> 5) + st * kTilesPerStep;
+        v4i b[2][4];
+        v16i cv[2];
+        load_tile(Bt, nl, b[0], cv[0]);
+        epilogue(2, pend_tile);
+        epilogue(3, pend_tile);
 #pragma unroll
         for (int t = 0; t < kTilesPerStep; ++t) {
-            const char* tile = Bt + t * 4096;
-            const v4i b0 = *reinterpret_cast<const v4i*>(tile);
-            const v4i b1 = *reinterpret_cast<const v4i*>(tile + 1024);
-            const v4i b2 = *reinterpret_cast<const v4i*>(tile + 2048);
-            const v4i b3 = *reinterpret_cast<const v4i*>(tile + 3072);
-            int c[16];
-            tile_consts(nl + t * 32, half, c);
-            v16i cv;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) cv[e] = c[e];
-            v16i acc[kQueryRB];
-#pragma unroll
-            for (int rb = 0; rb < kQueryRB; ++rb) {
-                v16i z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b0, pf[rb][0], cv, 0, 0, 0);
-                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b1, pf[rb][1], z, 0, 0, 0);
-                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b2, pf[rb][2], z, 0, 0, 0);
-                z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b3, pf[rb][3], z, 0, 0, 0);
-                acc[rb] = z;
+            if (t + 1 < kTilesPerStep) load_tile(Bt + (t + 1) * 4096, nl + (t + 1) * 32, b[(t + 1) & 1], cv[(t + 1) & 1]);
+            mma(0, b[t & 1], cv[t & 1]);
+            mma(1, b[t & 1], cv[t & 1]);
+            if (t > 0) {
+                epilogue(2, tile0 + t - 1);
+                epilogue(3, tile0 + t - 1);
             }
+            // issue order of this half: one MFMA, one LDS read of the next tile, three epilogue instructions, ...
 #pragma unroll
-            for (int rb = 0; rb < kQueryRB; ++rb) {
-                // plain min() on the accumulator registers (the compiler folds pairs into v_min3_i32): what
-                // reads an MFMA result must be visible to the compiler, which places the wait states the
-                // hardware needs between the matrix pipe's write and a vector read; inline assembly is not
-                int m = min(min(acc[rb][0], acc[rb][1]), acc[rb][2]);
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (t + 1 < kTilesPerStep) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (t > 0) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            mma(2, b[t & 1], cv[t & 1]);
+            mma(3, b[t & 1], cv[t & 1]);
+            epilogue(0, tile0 + t);
+            epilogue(1, tile0 + t);
 #pragma unroll
-                for (int e = 0; e < 6; ++e) m = min(min(m, acc[rb][3 + 2 * e]), acc[rb][4 + 2 * e]);
-                m = min(m, acc[rb][15]);
-                k2[rb] = med3i(k1[rb], k2[rb], m);           // k1 <= k2: the runner-up of {k1, k2, m}
-                kt[rb] = m < k1[rb] ? tile0 + t : kt[rb];    // strict: the first tile that holds the minimum
-                k1[rb] = min(k1[rb], m);
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
         }
+        pend_tile = tile0 + kTilesPerStep - 1;
         __syncthreads();
     }
+    epilogue(2, pend_tile);
+    epilogue(3, pend_tile);
 
 #pragma unroll
     for (int rb = 0; rb < kQueryRB; ++rb) {
@@ -561,9 +601,55 @@ __device__ __forceinline__ bool ratio_ok(const MatchRule& rule, long long d1, lo
     return rule.num2 <= 0 || d1 * rule.den2 < d2 * rule.num2;
 }
 
-// One wave per candidate: the 32 exact distances of its tile give the nearest row (lowest row among equal
-// distances), the exact d1 and the runner-up inside the tile; with the runner-up outside known up to its
-// parity bit the tests are decided unless that bit matters or the minimum is tied with another group.
+// minimum over each row of 16 lanes, valid in all 16 (four DPP steps, no LDS round trip)
+__device__ __forceinline__ int row16_min(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));   // row_mirror
+    return v;
+}
+
+// The tests of one candidate once its tile has been evaluated (wave-uniform values: scalar unit).
+// best / second: packed (x * 32 + row) minimum of the tile and the minimum without that row.
+__device__ __forceinline__ void resolve_decide(const MatchRule& rule, const SiftCandidates& cand, int p, int c, size_t o,
+                                               int tl, int y1, int y2, long long na, int best, int second, bool lane0)
+{
+    const int r1 = best & 31, x1 = best >> 5;
+    const long long d1 = (long long)x1 + na;
+    bool amb = y2 == y1 || (x1 >> 1) != y1;   // minimum tied with another group: the nearest row may lie there
+    bool pass = false;
+    if (!amb) {
+        const bool has_in = second != INT32_MAX, has_out = y2 < kYPad;
+        bool pr = true;
+        if (has_in || has_out) {
+            const long long in_x = has_in ? (long long)(second >> 5) : INT64_MAX / 4;
+            const long long out_lo = has_out ? 2ll * y2 : INT64_MAX / 4;
+            const bool pa = ratio_ok(rule, d1, min(in_x, out_lo) + na);
+            const bool pb = ratio_ok(rule, d1, min(in_x, out_lo + 1) + na);
+            if (pa != pb) amb = true;   // the parity bit of the runner-up decides
+            pr = pa;
+        }
+        pass = pr && (rule.max_dist < 0 || d1 <= rule.max_dist);
+    }
+    if (lane0) {
+        if (amb) {
+            const int k = atomicAdd(cand.rescan_count, 1);
+            cand.rescan_list[k] = make_int2(p, c);
+            cand.j1[o] = -1;
+        } else {
+            cand.j1[o] = pass ? tl * 32 + r1 : -1;
+            cand.d1[o] = (int)d1;
+        }
+    }
+}
+
+// Half a wave per candidate (lane = row of its tile, the whole 128-byte dot product per lane): the 32 exact
+// distances of the tile give the nearest row (lowest row among equal distances), the exact d1 and the
+// runner-up inside the tile; with the runner-up outside known up to its parity bit the tests are decided
+// unless that bit matters or the minimum is tied with another group.  The reductions are DPP steps and
+// lane reads, the decision runs on the scalar unit.
 constexpr int kResolveWaves = 4;
 __global__ __launch_bounds__(kResolveWaves * 64)
 void sift_resolve_kernel(const SiftPair* __restrict__ pairs, int slices, MatchRule rule, SiftCandidates cand)
@@ -572,50 +658,58 @@ void sift_resolve_kernel(const SiftPair* __restrict__ pairs, int slices, MatchRu
     const int p = item / slices, sl = item % slices;
     const SiftPair pw = pairs[p];
     const int ncand = cand.count[p];
-    const int lane = threadIdx.x & 63, lane5 = lane & 31, half = lane >> 5;
+    const int lane = threadIdx.x & 63, r = lane & 31, hw = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int c = sl * kResolveWaves + wave; c < ncand; c += slices * kResolveWaves) {
-        const size_t o = pw.out0_off + c;
-        const int i = cand.i0[o], tl = cand.j1[o], y1 = cand.d1[o], y2 = cand.aux[o];
-        const int8_t* qsrc = pw.fragA + (size_t)(i >> 5) * kTileBytes + (half * 32 + (i & 31)) * 16;
-        v4i qa[4];
+    const int stride = slices * kResolveWaves;
+    const int8_t VSM_GLB* fragA = (const int8_t VSM_GLB*)pw.fragA;
+    const int8_t VSM_GLB* fragB = (const int8_t VSM_GLB*)pw.fragB;
+    const int32_t VSM_GLB* nrmA = (const int32_t VSM_GLB*)pw.nrmA;
+    const int32_t VSM_GLB* nrmB = (const int32_t VSM_GLB*)pw.nrmB;
+    // A wave takes candidates first, first + stride, ...  Their records are read 64 at a time (lane k: the
+    // k-th of the batch), so that a round -- two candidates, one per half wave -- costs one round trip to
+    // memory (query row + tile), not two.
+    const int first = sl * kResolveWaves + wave;
+    for (int base = first; base < ncand; base += 64 * stride) {
+        const int cl = base + lane * stride;
+        const bool live = cl < ncand;
+        const size_t ol = pw.out0_off + (live ? cl : base);
+        const int rec_i = cand.i0[ol], rec_t = cand.j1[ol], rec_y1 = cand.d1[ol], rec_y2 = cand.aux[ol];
+        const int rec_na = nrmA[rec_i] >> 8;
+        const int nb = min(64, (ncand - base + stride - 1) / stride);   // candidates in this batch
+        for (int k = 0; k < nb; k += 2) {
+            const bool two = k + 1 < nb;
+            const int kb = two ? k + 1 : k;
+            // wave-uniform copies of both candidates' records; each half works on its own
+            const int iA = __builtin_amdgcn_readlane(rec_i, k), iB = __builtin_amdgcn_readlane(rec_i, kb);
+            const int tA = __builtin_amdgcn_readlane(rec_t, k), tB = __builtin_amdgcn_readlane(rec_t, kb);
+            const int i = hw ? iB : iA, tl = hw ? tB : tA;
+            const int8_t VSM_GLB* q = fragA + (size_t)(i >> 5) * kTileBytes + (i & 31) * 16;
+            const int8_t VSM_GLB* t = fragB + (size_t)tl * kTileBytes + r * 16;
+            int dot = 0;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qa[s] = *reinterpret_cast<const v4i*>(qsrc + s * 1024);
-        const int x = tile_row_x(pw, tl, lane, qa);
-        // |x| < 2^23: value and row in one key
-        const int key = x == INT32_MAX ? INT32_MAX : x * 32 + lane5;
-        const int best = wave_min32(key);
-        const int r1 = best & 31, x1 = best >> 5;
-        const int key2 = wave_min32(lane5 == r1 ? INT32_MAX : key);
-        const long long na = pw.nrmA[i] >> 8;
-        const long long d1 = (long long)x1 + na;
-        bool amb = y2 == y1 || (x1 >> 1) != y1;   // minimum tied with another group: the nearest row may lie there
-        bool pass = false;
-        if (!amb) {
-            const bool has_in = key2 != INT32_MAX, has_out = y2 < kYPad;
-            bool pr = true;
-            if (has_in || has_out) {
-                const long long in_x = has_in ? (long long)(key2 >> 5) : INT64_MAX / 4;
-                const long long out_lo = has_out ? 2ll * y2 : INT64_MAX / 4;
-                const bool pa = ratio_ok(rule, d1, min(in_x, out_lo) + na);
-                const bool pb = ratio_ok(rule, d1, min(in_x, out_lo + 1) + na);
-                if (pa != pb) amb = true;   // the parity bit of the runner-up decides
-                pr = pa;
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    dot = dot16(*reinterpret_cast<const v4i VSM_GLB*>(q + s * 1024 + h * 512),
+                                *reinterpret_cast<const v4i VSM_GLB*>(t + s * 1024 + h * 512), dot);
             }
-            pass = pr && (rule.max_dist < 0 || d1 <= rule.max_dist);
-        }
-#ifdef VSM_DEBUG_RESOLVE
-        if (lane == 0) printf("resolve c=%d i=%d tl=%d y1=%d y2=%d x1=%d r1=%d key2=%d amb=%d pass=%d\n", c, i, tl, y1, y2, x1, r1, key2, (int)amb, (int)pass);
-#endif
-        if (lane == 0) {
-            if (amb) {
-                const int k = atomicAdd(cand.rescan_count, 1);
-                cand.rescan_list[k] = make_int2(p, c);
-                cand.j1[o] = -1;
-            } else {
-                cand.j1[o] = pass ? tl * 32 + r1 : -1;
-                cand.d1[o] = (int)d1;
-            }
+            const int row = tl * 32 + r;
+            // |x| < 2^23: value and row in one key
+            const int key = row < pw.nB ? ((nrmB[row] >> 8) - 2 * dot) * 32 + r : INT32_MAX;
+            const int m = row16_min(key);
+            const int bestA = min(__builtin_amdgcn_readlane(m, 0), __builtin_amdgcn_readlane(m, 16));
+            const int bestB = min(__builtin_amdgcn_readlane(m, 32), __builtin_amdgcn_readlane(m, 48));
+            const int mine = hw ? bestB : bestA;
+            const int m2 = row16_min(r == (mine & 31) ? INT32_MAX : key);
+            const int secA = min(__builtin_amdgcn_readlane(m2, 0), __builtin_amdgcn_readlane(m2, 16));
+            const int secB = min(__builtin_amdgcn_readlane(m2, 32), __builtin_amdgcn_readlane(m2, 48));
+            const int cA = base + k * stride;
+            resolve_decide(rule, cand, p, cA, pw.out0_off + cA, tA, __builtin_amdgcn_readlane(rec_y1, k),
+                           __builtin_amdgcn_readlane(rec_y2, k), __builtin_amdgcn_readlane(rec_na, k), bestA, secA, lane == 0);
+            if (two)
+                resolve_decide(rule, cand, p, cA + stride, pw.out0_off + cA + stride, tB, __builtin_amdgcn_readlane(rec_y1, kb),
+                               __builtin_amdgcn_readlane(rec_y2, kb), __builtin_amdgcn_readlane(rec_na, kb), bestB, secB,
+                               lane == 0);
         }
     }
 }
@@ -659,9 +753,6 @@ void sift_rescan_kernel(const SiftPair* __restrict__ pairs, MatchRule rule, Sift
         bool pass = wx != INT32_MAX;
         if (pass && x2 != INT32_MAX) pass = ratio_ok(rule, d1, (long long)x2 + na);
         if (pass && rule.max_dist >= 0 && d1 > rule.max_dist) pass = false;
-#ifdef VSM_DEBUG_RESOLVE
-        if (lane == 0) printf("rescan e=%d i=%d wx=%d wrow=%d x2=%d pass=%d\n", e, i, wx, wrow, x2, (int)pass);
-#endif
         if (lane == 0) {
             cand.j1[o] = pass ? wrow : -1;
             cand.d1[o] = (int)d1;
