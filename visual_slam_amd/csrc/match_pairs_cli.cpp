@@ -8,6 +8,7 @@
 #include "../../include/vsm.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -377,7 +378,10 @@ int main(int argc, char** argv)
     std::mutex mu;
     std::condition_variable cv;
     int filled[2] = {0, 0};   // 0 = free for the GPU side, 1 = waiting for the writer
-    bool finished = false, write_failed = false;
+    bool finished = false;
+    // set by the writer thread, read by the GPU thread: the message is published before the flag
+    // (release / acquire), and only the writer thread reads the flag relaxed
+    std::atomic<bool> write_failed{false};
     std::string write_error;
 
     vsm_matwriter* mw = o.write_mat ? vsm_mat_writer_open(o.num, 0) : nullptr;
@@ -395,16 +399,16 @@ int main(int argc, char** argv)
                 const std::string n0 = std::to_string(ia) + o.name_ext, n1 = std::to_string(ib) + o.name_ext;
                 if (vsm_matchtxt_write(tw, n0.c_str(), n1.c_str(), b.idx0.data() + b.off[k], b.idx1.data() + b.off[k], nm,
                                        count[ia]) < 0) {
-                    write_failed = true;
                     write_error = "write error on " + o.out;
+                    write_failed.store(true, std::memory_order_release);
                 }
                 if (o.write_mat && !write_failed) {
                     const std::string p0 = o.sift_dir + "/" + std::to_string(ia), p1 = o.sift_dir + "/" + std::to_string(ib);
                     const int rc = vsm_mat_writer_put(mw, p0.c_str(), p1.c_str(), count[ia], count[ib], nm,
                                                       b.idx0.data() + b.off[k], b.idx1.data() + b.off[k]);
                     if (rc < 0) {
-                        write_failed = true;
                         write_error = "cannot write .mat for pair " + std::to_string(ia) + " " + std::to_string(ib);
+                        write_failed.store(true, std::memory_order_release);
                     }
                 }
                 if (verify && !write_failed) {
@@ -412,14 +416,14 @@ int main(int argc, char** argv)
                     const int32_t* q0 = b.in0.data() + b.in_off[k];
                     const int32_t* q1 = b.in1.data() + b.in_off[k];
                     if (tw_in && vsm_matchtxt_write(tw_in, n0.c_str(), n1.c_str(), q0, q1, nin, count[ia]) < 0) {
-                        write_failed = true;
                         write_error = "write error on " + o.inlier_out;
+                        write_failed.store(true, std::memory_order_release);
                     }
                     if (o.write_mat && !write_failed) {
                         const std::string p0 = o.sift_dir + "/" + std::to_string(ia), p1 = o.sift_dir + "/" + std::to_string(ib);
                         if (vsm_mat_writer_put_fmatch(mw, p0.c_str(), p1.c_str(), nin, q0, q1, b.F.data() + (size_t)k * 9) < 0) {
-                            write_failed = true;
                             write_error = "cannot write inlier record for pair " + std::to_string(ia) + " " + std::to_string(ib);
+                            write_failed.store(true, std::memory_order_release);
                         }
                     }
                 }
@@ -463,7 +467,7 @@ int main(int argc, char** argv)
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return filled[cur] == 0; });
         }
-        if (write_failed) break;
+        if (write_failed.load(std::memory_order_acquire)) break;
         Batch& b = batches[cur];
         const long long lo = k * o.batch;
         const int take = (int)std::min<long long>(o.batch, npairs - lo);
@@ -518,7 +522,7 @@ int main(int argc, char** argv)
     cv.notify_all();
     writer.join();
     if (gpu_failed) return 1;
-    if (write_failed) {
+    if (write_failed.load(std::memory_order_acquire)) {
         fprintf(stderr, "%s\n", write_error.c_str());
         return 1;
     }
