@@ -156,7 +156,10 @@ long long vsm_fetch_matches(vsm_ctx* ctx, int64_t* offsets, int32_t* idx0, int32
 /* For every query row: nearest database row (lowest index on ties), its key, and the
  * runner-up key.  u8: d1/d2 are int32 squared L2 (VSM_NO_SECOND when the database has
  * one row).  f32: float; DOT keys are dot products (larger is better), L2 keys are
- * squared distances.  idx2 may be NULL.  Brute-force 1-NN of
+ * squared distances: the two best rows are found by the key |b|^2 - 2 a.b the matrix cores
+ * compute, then ordered, and their distances reported, in difference form sum (a[k] - b[k])^2
+ * (what the reference ranks by, model_2_0.py:68; exact to 1e-5 relative for near-duplicates too).
+ * idx2 may be NULL.  Brute-force 1-NN of
  * NearestEmbedFunc.forward (model_2_0.py:43-78) is the k=1 part of this call. */
 int vsm_knn2(vsm_ctx* ctx, int set_q, int set_db, int metric,
              int32_t* idx1, int32_t* idx2, void* d1, void* d2);

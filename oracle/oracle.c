@@ -163,6 +163,38 @@ static float* sqnorms_f32(const float* X, int n, int dim)
 
 static inline float worst_f32(int metric) { return metric == ORC_METRIC_DOT ? -INFINITY : INFINITY; }
 
+/* Squared distance in difference form, k ascending: the form the reference ranks by
+ * (model_2_0.py:68, torch.norm(x - emb, 2, 1)); no cancellation for near-duplicates. */
+static inline float diffsq_f32(const float* a, const float* b, int dim)
+{
+    float d = 0.0f;
+    for (int k = 0; k < dim; ++k) {
+        const float t = a[k] - b[k];
+        d = fmaf(t, t, d);
+    }
+    return d;
+}
+
+/* L2 searches: the two best rows are FOUND by the key nb - 2 a.b (what the matrix cores rank by; first
+ * index on equal keys), then ORDERED, and their distances reported, in difference form: s1 <= s2, and on
+ * equal distances the lower row first. */
+static void l2_finish(const float* a, const float* B, int dim, int32_t* bi, int32_t bi2, float* s1, float* s2)
+{
+    if (*bi < 0) return;
+    float d1 = diffsq_f32(a, B + (size_t)*bi * dim, dim);
+    if (bi2 < 0) {
+        *s1 = d1;
+        return;
+    }
+    float d2 = diffsq_f32(a, B + (size_t)bi2 * dim, dim);
+    if (d2 < d1 || (d2 == d1 && bi2 < *bi)) {
+        float t = d1; d1 = d2; d2 = t;
+        *bi = bi2;
+    }
+    *s1 = d1;
+    *s2 = d2;
+}
+
 void orc_knn2_f32(const float* A, int n, const float* B, int m, int dim, int metric,
                   int threads, int32_t* idx1, float* s1, float* s2)
 {
@@ -171,23 +203,19 @@ void orc_knn2_f32(const float* A, int n, const float* B, int m, int dim, int met
 #pragma omp parallel for num_threads(threads) schedule(static)
     for (int i = 0; i < n; ++i) {
         float b1 = worst_f32(metric), b2 = worst_f32(metric);
-        int32_t bi = -1;
+        int32_t bi = -1, bi2 = -1;
         const float* a = A + (size_t)i * dim;
         for (int j = 0; j < m; ++j) {
             float k = key_f32(a, B + (size_t)j * dim, dim, metric, nb[j]);
             if (bi < 0 || better_f32(k, b1, metric)) {
-                b2 = b1;
+                b2 = b1; bi2 = bi;
                 b1 = k;
                 bi = j;
-            } else if (better_f32(k, b2, metric)) {
-                b2 = k;
+            } else if (bi2 < 0 || better_f32(k, b2, metric)) {
+                b2 = k; bi2 = j;
             }
         }
-        if (metric == ORC_METRIC_L2) {
-            float na = orc_dot_f32(a, a, dim);
-            if (bi >= 0) b1 = fmaxf(b1 + na, 0.0f);
-            if (m >= 2) b2 = fmaxf(b2 + na, 0.0f);
-        }
+        if (metric == ORC_METRIC_L2) l2_finish(a, B, dim, &bi, bi2, &b1, &b2);
         idx1[i] = bi;
         s1[i] = b1;
         s2[i] = b2;
@@ -198,27 +226,10 @@ void orc_knn2_f32(const float* A, int n, const float* B, int m, int dim, int met
 void orc_colbest_f32(const float* A, int n, const float* B, int m, int dim, int metric,
                      int threads, int32_t* cidx, float* cs)
 {
-    if (threads < 1) threads = 1;
-    float* na = sqnorms_f32(A, n, dim);
-#pragma omp parallel for num_threads(threads) schedule(static)
-    for (int j = 0; j < m; ++j) {
-        float b1 = worst_f32(metric);
-        int32_t bi = -1;
-        const float* b = B + (size_t)j * dim;
-        for (int i = 0; i < n; ++i) {
-            /* the train-side ranking uses the query norm as the varying term */
-            float d = orc_dot_f32(A + (size_t)i * dim, b, dim);
-            float k = metric == ORC_METRIC_DOT ? d : fmaf(-2.0f, d, na[i]);
-            if (bi < 0 || better_f32(k, b1, metric)) {
-                b1 = k;
-                bi = i;
-            }
-        }
-        if (metric == ORC_METRIC_L2 && bi >= 0) b1 = fmaxf(b1 + orc_dot_f32(b, b, dim), 0.0f);
-        cidx[j] = bi;
-        cs[j] = b1;
-    }
-    free(na);
+    /* the train-side best is the search with the roles exchanged (every row of B against A) */
+    float* s2 = (float*)malloc(sizeof(float) * (size_t)(m > 0 ? m : 1));
+    orc_knn2_f32(B, m, A, n, dim, metric, threads, cidx, cs, s2);
+    free(s2);
 }
 
 static int accept_f32(float s1, float s2, int have2, int metric, const orc_params* p)
@@ -307,15 +318,19 @@ void orc_nearest_embed_f32(const float* x, int batch, int dim, int npts,
         int b = bp / npts, pt = bp % npts;
         float* q = (float*)malloc(sizeof(float) * (size_t)dim);
         for (int d = 0; d < dim; ++d) q[d] = x[((size_t)b * dim + d) * npts + pt];
-        float best = INFINITY;
-        int bi = -1;
+        float best = INFINITY, second = INFINITY;
+        int32_t bi = -1, bi2 = -1;
         for (int c = 0; c < k; ++c) {
             float key = key_f32(q, E + (size_t)c * dim, dim, ORC_METRIC_L2, ne[c]);
             if (bi < 0 || key < best) {
+                second = best; bi2 = bi;
                 best = key;
                 bi = c;
+            } else if (bi2 < 0 || key < second) {
+                second = key; bi2 = c;
             }
         }
+        l2_finish(q, E, dim, &bi, bi2, &best, &second);
         argmin[bp] = bi;
         if (result)
             for (int d = 0; d < dim; ++d)

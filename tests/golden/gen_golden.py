@@ -62,6 +62,30 @@ def gen_nearest_embed():
              x2=x2.numpy(), emb2=emb2.numpy(), result2=res2.numpy(), argmin2=argmin2.numpy())
 
 
+def gen_nearest_embed_near_ties():
+    """Near-ties, where a distance computed as |x|^2 + |e|^2 - 2 x.e drowns in rounding and only the
+    difference form the reference uses (norm of x - e) ranks correctly: codes in pairs 1e-6 apart, points
+    1e-4 .. 1e-2 away from a code of such a pair."""
+    sys.path.insert(0, os.path.join(REF, "Graph_Idea"))
+    from model.model_2_0 import nearest_embed
+
+    g = torch.Generator().manual_seed(4321)
+    k, dim, npts = 128, 256, 96
+    emb = torch.rand((dim, k), generator=g)
+    for c in range(0, 64, 2):       # 32 pairs of codes 1e-6 apart (per component, random signs)
+        emb[:, c + 1] = emb[:, c] + 1e-6 * torch.sign(torch.randn(dim, generator=g))
+    x = torch.rand((2, dim, npts), generator=g)
+    for b in range(2):
+        for p in range(npts):
+            c = int(torch.randint(0, 64, (1,), generator=g))
+            u = torch.randn(dim, generator=g)
+            u /= u.norm()
+            x[b, :, p] = emb[:, c] + (10.0 ** float(-4.0 + 2.0 * torch.rand(1, generator=g))) * u
+    res, argmin = nearest_embed(x, emb)
+    np.savez(os.path.join(OUT, "nearest_embed_near_ties.npz"), x=x.numpy(), emb=emb.numpy(), result=res.numpy(),
+             argmin=argmin.numpy())
+
+
 def gen_mutual_block():
     sys.path.insert(0, os.path.join(REF, "Others/SuperPoint_data"))
     from models.superglue import arange_like
@@ -140,6 +164,7 @@ def gen_text_formats():
 
 if __name__ == "__main__":
     gen_nearest_embed()
+    gen_nearest_embed_near_ties()
     gen_mutual_block()
     gen_text_formats()
     print("fixtures written to", OUT)

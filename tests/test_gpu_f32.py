@@ -1,9 +1,9 @@
 """GPU parity: float descriptors (SuperPoint-256 style) through the C ABI against the CPU oracle
 and the reference-generated fixtures.
 
-Bar: indices bit-exact; scores/distances bit-exact against the oracle's k-ascending fmaf chain
-(the f32-input MFMA is that chain), and within 1e-5 relative (2e-6 absolute floor, for distances
-of near-duplicates where |a|^2 + |b|^2 - 2ab cancels) of a float64 computation."""
+Bar: indices bit-exact; scores/distances bit-exact against the oracle (dot products: the k-ascending
+fmaf chain, which the f32-input MFMA is; squared distances: the k-ascending fmaf chain of (a - b)^2 on the
+two best rows), and within 1e-5 relative of a float64 computation, near-duplicates included."""
 import math
 import os
 
@@ -59,7 +59,8 @@ def test_knn2_non_unit_vectors_l2(matcher):
     s0, s1 = matcher.upload_f32(a), matcher.upload_f32(b)
     gi, gd1, gd2 = matcher.knn2(s0, s1, vsm.METRIC_L2)
     np.testing.assert_array_equal(gi, D.argmin(1))
-    np.testing.assert_allclose(gd1, D.min(1), rtol=1e-5, atol=2e-6 * 256)
+    np.testing.assert_allclose(gd1, D.min(1), rtol=1e-5, atol=0)
+    np.testing.assert_allclose(gd2, np.sort(D, 1)[:, 1], rtol=1e-5, atol=0)
     matcher.release(s0)
     matcher.release(s1)
 
@@ -132,6 +133,43 @@ def test_nearest_embed_fixture(matcher):
         np.testing.assert_array_equal(res, z["result" + sfx])
         ores, oam = orc.nearest_embed_f32(z["x" + sfx], z["emb" + sfx])
         np.testing.assert_array_equal(am, oam)
+
+
+def test_nearest_embed_near_ties_fixture(matcher):
+    """Codes in pairs 1e-6 apart, points 1e-4 .. 1e-2 from one of them: the argmin must be the one the
+    reference's nearest_embed returned (tests/golden/gen_golden.py), which ranks by the norm of the difference."""
+    z = np.load(os.path.join(G, "nearest_embed_near_ties.npz"))
+    res, am = host.nearest_embed(matcher, z["x"], z["emb"])
+    np.testing.assert_array_equal(am, z["argmin"])
+    np.testing.assert_array_equal(res, z["result"])
+
+
+def test_near_duplicates_l2_relative_tolerance(matcher):
+    """Near-duplicates at 1e-5 .. 1e-1: distances within 1e-5 RELATIVE of float64, no absolute floor; and the
+    ratio test and mutual check on them equal the oracle's."""
+    a, b = synth.superpoint_pair(400, 600, 256, seed=12)
+    rng = np.random.default_rng(13)
+    for r, eps in zip(range(0, 200, 4), np.logspace(-5, -1, 50)):
+        b[r + 1] = a[r] + (eps / 16.0 * rng.standard_normal(256)).astype(np.float32)
+        b[r + 2] = b[r + 1] + (1e-6 / 16.0 * rng.standard_normal(256)).astype(np.float32)   # two rows 1e-6 apart
+    s0, s1 = matcher.upload_f32(a), matcher.upload_f32(b)
+    try:
+        gi, gi2, gd1, gd2 = matcher.knn2(s0, s1, vsm.METRIC_L2, want_idx2=True)
+        D = ((a[:, None, :].astype(np.float64) - b[None].astype(np.float64)) ** 2).sum(-1)
+        np.testing.assert_allclose(gd1, D.min(1), rtol=1e-5, atol=0)
+        np.testing.assert_allclose(gd2, np.sort(D, 1)[:, 1], rtol=1e-5, atol=0)
+        oi, od1, od2 = orc.knn2_f32(a, b, orc.METRIC_L2)
+        np.testing.assert_array_equal(gi, oi)
+        np.testing.assert_array_equal(gd1, od1)
+        np.testing.assert_array_equal(gd2, od2)
+        for mutual in (True, False):
+            g0, g1 = matcher.match_pair_dense(s0, s1, ratio=0.8, mutual=mutual, metric=vsm.METRIC_L2)
+            o0, o1, _, _ = orc.match_dense_f32(a, b, orc.METRIC_L2, orc.params((4, 5), mutual))
+            np.testing.assert_array_equal(g0, o0)
+            np.testing.assert_array_equal(g1, o1)
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)
 
 
 def test_database_slices_merge(matcher):

@@ -129,8 +129,23 @@ def test_knn_f32_against_float64():
     i, s1, s2 = orc.knn2_f32(a, b, orc.METRIC_DOT)
     np.testing.assert_array_equal(i, S.argmax(1))
     np.testing.assert_allclose(s1, S.max(1), rtol=1e-5, atol=1e-6)
+    rng = np.random.default_rng(44)
+    for r, eps in zip(range(0, 40, 4), np.logspace(-5, -1, 10)):      # near-duplicates at 1e-5 .. 1e-1
+        b[r + 1] = a[r] + (eps / 16.0 * rng.standard_normal(256)).astype(np.float32)
     D = ((a[:, None, :].astype(np.float64) - b[None].astype(np.float64)) ** 2).sum(-1)
     i, d1, d2 = orc.knn2_f32(a, b, orc.METRIC_L2)
     np.testing.assert_array_equal(i, D.argmin(1))
-    np.testing.assert_allclose(d1, D.min(1), rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(d2, np.sort(D, 1)[:, 1], rtol=1e-5, atol=2e-6)
+    # difference-form distances: relative tolerance only, near-duplicates included
+    np.testing.assert_allclose(d1, D.min(1), rtol=1e-5, atol=0)
+    np.testing.assert_allclose(d2, np.sort(D, 1)[:, 1], rtol=1e-5, atol=0)
+    assert D.min() < 1e-9          # the planted near-duplicates are part of the comparison
+
+
+def test_nearest_embed_near_ties_fixture():
+    """Codes in pairs 1e-6 apart and points 1e-4 .. 1e-2 from them (made by calling the reference's
+    nearest_embed, tests/golden/gen_golden.py): the oracle finds the reference's argmin everywhere, which a
+    distance of the form |x|^2 + |e|^2 - 2 x.e cannot (its rounding error exceeds the gaps)."""
+    z = np.load(os.path.join(G, "nearest_embed_near_ties.npz"))
+    res, am = orc.nearest_embed_f32(z["x"], z["emb"])
+    np.testing.assert_array_equal(am, z["argmin"])
+    np.testing.assert_array_equal(res, z["result"])

@@ -35,7 +35,8 @@ size_t f32_scratch_bytes(const F32Problem& pr, bool want_col);
 
 void launch_f32_transform(const float* src, int n, int n_pad, int dim, bool dim_major,
                           float* frag, float* nrm, hipStream_t s);
-// Query side: j1/j2 (indices), k1/k2 (DOT: dot products; L2: squared distances), nA entries.
+// Query side: j1/j2 (indices), k1/k2 (DOT: dot products; L2: the ranking key turned into a squared distance,
+// before launch_f32_l2_finish replaces it by the difference form), nA entries.
 // Train side (optional): cidx/ck, nB entries.
 void launch_f32_knn(const F32Problem& pr, int32_t* j1, int32_t* j2, float* k1, float* k2,
                     int32_t* cidx, float* ck, void* scratch, hipStream_t s);
@@ -113,5 +114,11 @@ size_t coarse_scratch_bytes(const CoarseTotals& t);
 void launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
                        int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow,
                        hipStream_t s);
+
+// L2 searches only (problems of the other metric are skipped): orders each query's two best rows by the
+// difference-form squared distance and stores those distances in k1 / k2.  Problems come from device memory
+// (d_probs[nprobs]) or, with `single`, as one problem by value; max_rows = most query rows of a problem.
+void launch_f32_l2_finish(const CoarseProblem* d_probs, int nprobs, int max_rows, const CoarseProblem* single,
+                          int32_t* j1, int32_t* j2, float* k1, float* k2, hipStream_t s);
 
 }  // namespace vsm

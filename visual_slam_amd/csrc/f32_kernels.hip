@@ -350,4 +350,63 @@ void launch_f32_knn(const F32Problem& pr, int32_t* j1, int32_t* j2, float* k1, f
                            pr, pr.nA_pad / 32, colpart, cidx, ck);
 }
 
+// ---------------------------------------------------------------------------------
+// L2 searches: the two best rows ordered, and their distances reported, in difference form
+// ---------------------------------------------------------------------------------
+// The matrix cores rank by the key |b|^2 - 2 a.b, whose rounding error (about 1e-7 of |a|^2 + |b|^2)
+// exceeds the squared distance of near-duplicates.  The reference ranks by the norm of the difference
+// (Graph_Idea/model/model_2_0.py:68), which has no cancellation.  So the two best rows are FOUND by the key
+// and then ordered by d = the k-ascending fmaf chain of (a[k] - b[k])^2 (lower row first on equal d); k1 and
+// k2 become those distances.  One thread per query; rows come from the plain row-major copies.
+__global__ void f32_l2_finish_kernel(const CoarseProblem* __restrict__ probs, CoarseProblem single, int use_single,
+                                     int32_t* __restrict__ j1, int32_t* __restrict__ j2,
+                                     float* __restrict__ k1, float* __restrict__ k2)
+{
+    const CoarseProblem& p = use_single ? single : probs[blockIdx.y];
+    if (p.pr.metric != 1) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.pr.nA) return;
+    const size_t o = (size_t)p.out_off + i;
+    int a1 = j1[o], a2 = j2[o];
+    if (a1 < 0) return;
+    const int dimp = f32_dimp(p.pr.dim);
+    const float4* qa = reinterpret_cast<const float4*>(p.rowsA + (size_t)i * dimp);
+    const float4* r1 = reinterpret_cast<const float4*>(p.rowsB + (size_t)a1 * dimp);
+    const float4* r2 = reinterpret_cast<const float4*>(p.rowsB + (size_t)(a2 < 0 ? a1 : a2) * dimp);
+    float d1 = 0.0f, d2 = 0.0f;
+    for (int g = 0; g < dimp / 4; ++g) {     // the padding columns are zero in every row: they add exact zeros
+        const float4 a = qa[g], x = r1[g], y = r2[g];
+        float t;
+        t = a.x - x.x; d1 = fmaf(t, t, d1);
+        t = a.y - x.y; d1 = fmaf(t, t, d1);
+        t = a.z - x.z; d1 = fmaf(t, t, d1);
+        t = a.w - x.w; d1 = fmaf(t, t, d1);
+        t = a.x - y.x; d2 = fmaf(t, t, d2);
+        t = a.y - y.y; d2 = fmaf(t, t, d2);
+        t = a.z - y.z; d2 = fmaf(t, t, d2);
+        t = a.w - y.w; d2 = fmaf(t, t, d2);
+    }
+    if (a2 < 0) {           // a database of one row has no runner-up
+        k1[o] = d1;
+        return;
+    }
+    if (d2 < d1 || (d2 == d1 && a2 < a1)) {
+        const float t = d1; d1 = d2; d2 = t;
+        const int u = a1; a1 = a2; a2 = u;
+    }
+    j1[o] = a1;
+    j2[o] = a2;
+    k1[o] = d1;
+    k2[o] = d2;
+}
+
+void launch_f32_l2_finish(const CoarseProblem* d_probs, int nprobs, int max_rows, const CoarseProblem* single,
+                          int32_t* j1, int32_t* j2, float* k1, float* k2, hipStream_t s)
+{
+    if (nprobs <= 0 || max_rows <= 0) return;
+    const dim3 grid((max_rows + 255) / 256, nprobs);
+    hipLaunchKernelGGL(f32_l2_finish_kernel, grid, dim3(256), 0, s, d_probs, single ? *single : CoarseProblem{},
+                       single ? 1 : 0, j1, j2, k1, k2);
+}
+
 }  // namespace vsm

@@ -746,9 +746,16 @@ int queue_coarse(vsm_ctx* c, std::vector<CoarseProblem>& probs, int dim, size_t 
     c->flag_dev = c->d_probs.as<int>();
     if (extra_dev) *extra_dev = c->d_probs.as<char>() + 256 + pbytes;
     if (probs.empty()) return VSM_OK;
-    launch_bf16_batch(reinterpret_cast<const CoarseProblem*>(c->d_probs.as<char>() + 256), (int)probs.size(), dim, t,
+    const CoarseProblem* d_probs = reinterpret_cast<const CoarseProblem*>(c->d_probs.as<char>() + 256);
+    launch_bf16_batch(d_probs, (int)probs.size(), dim, t,
                       c->d_knnj.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_knn1.as<float>(), c->d_knn2.as<float>(),
                       c->d_coarse.p, c->flag_dev, c->stream);
+    if (probs[0].pr.metric == VSM_METRIC_L2) {   // one metric per submission
+        int max_rows = 0;
+        for (const CoarseProblem& p : probs) max_rows = std::max(max_rows, p.pr.nA);
+        launch_f32_l2_finish(d_probs, (int)probs.size(), max_rows, nullptr, c->d_knnj.as<int32_t>(), c->d_rrj.as<int32_t>(),
+                             c->d_knn1.as<float>(), c->d_knn2.as<float>(), c->stream);
+    }
     return VSM_OK;
 }
 
@@ -804,11 +811,26 @@ int run_f32_knn(vsm_ctx* c, const DescSet* A, const DescSet* B, int metric, bool
     r->k2 = c->d_knn2.as<float>();
     r->cidx = r->j1 + A->n_pad;
     r->ck = r->k1 + A->n_pad;
-    const CoarseProblem p = make_problem(A, B, metric);
+    CoarseProblem p = make_problem(A, B, metric);
+    p.out_off = 0;
     if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
-    HIPCHK(c, c->d_colpart.ensure(f32_scratch_bytes(p.pr, want_col)));
-    launch_f32_knn(p.pr, r->j1, r->j2, r->k1, r->k2, want_col ? r->cidx : nullptr, want_col ? r->ck : nullptr,
-                   c->d_colpart.p, c->stream);
+    if (metric == VSM_METRIC_L2) {
+        // the train side of a mutual check is the same search with the roles exchanged, as on the fast path:
+        // both directions get their two best rows ordered in difference form
+        HIPCHK(c, c->d_colpart.ensure(std::max(f32_scratch_bytes(p.pr, false), f32_scratch_bytes(make_problem(B, A, metric).pr, false))));
+        launch_f32_knn(p.pr, r->j1, r->j2, r->k1, r->k2, nullptr, nullptr, c->d_colpart.p, c->stream);
+        launch_f32_l2_finish(nullptr, 1, A->n, &p, r->j1, r->j2, r->k1, r->k2, c->stream);
+        if (want_col) {
+            CoarseProblem q = make_problem(B, A, metric);
+            q.out_off = A->n_pad;
+            launch_f32_knn(q.pr, r->cidx, r->j2 + A->n_pad, r->ck, r->k2 + A->n_pad, nullptr, nullptr, c->d_colpart.p, c->stream);
+            launch_f32_l2_finish(nullptr, 1, B->n, &q, r->j1, r->j2, r->k1, r->k2, c->stream);
+        }
+    } else {
+        HIPCHK(c, c->d_colpart.ensure(f32_scratch_bytes(p.pr, want_col)));
+        launch_f32_knn(p.pr, r->j1, r->j2, r->k1, r->k2, want_col ? r->cidx : nullptr, want_col ? r->ck : nullptr,
+                       c->d_colpart.p, c->stream);
+    }
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
         c->R().ev_valid = true;
