@@ -290,7 +290,10 @@ int vsm_train_vocabulary(vsm_ctx* ctx, const int32_t* sets, int nimg, int nwords
  * release it with vsm_release_set. */
 int vsm_sample_rows_u8(vsm_ctx* ctx, const int32_t* sets, int nimg, int stride);
 /* MatchFile::WritePMatch(image1, image2, fc1, fc2, NM, matches) (MatchFile.cpp:751-832):
- * image paths without extension; writes <image1>.mat and <image2>.mat.
+ * image paths without extension; writes <image1>.mat and <image2>.mat.  Re-writing a pair with more
+ * matches than its block holds moves the record to the end of the file as MoveRecordToEnd does
+ * (MatchFile.cpp:422-453), bookkeeping quirks included; a full directory doubles as in AddImageMatch
+ * (:494-560).
  * reservation = MatchFile::SetRecordReservation (MatchFile.h:244); pass 0 for the
  * reference default of 20. */
 int vsm_mat_write_pmatch(const char* image1, const char* image2, int fc1, int fc2,
@@ -317,7 +320,11 @@ int vsm_mat_get_match_count(const char* image, const char* other, int* nm, int* 
 /* MatchFile::WriteFMatch (MatchFile.cpp:596-605 -> WriteIMatch :643-748): geometry (NF, F) and the
  * inlier index lists into the record of the pair in both images' files (F transposed and the rows
  * swapped in the second, as SetGeometryR and :735-746 do).  The pair's putative record must exist
- * (vsm_mat_write_pmatch).  Returns 1, 0 if a file has no such record, or a negative code. */
+ * (vsm_mat_write_pmatch).  Returns 1, 0 if a file has no such record, or a negative code.
+ * NOT reproduced: the reference's re-allocation branch (MatchFile.cpp:690-719), taken when the record's
+ * block cannot hold the inlier lists; there the reference moves the directory entry and leaves the
+ * putative lists behind.  No record written by vsm_mat_write_pmatch reaches it with NF <= NM; a block
+ * that is too small returns VSM_EUNSUPPORTED. */
 int vsm_mat_write_fmatch(const char* image1, const char* image2, int nf, const int32_t* idx1,
                          const int32_t* idx2, const float* F);
 /* MatchFile::GetIMatch / GetIMatchR (MatchFile.cpp:961-1084): F[9], *nf and up to cap inlier pairs;

@@ -595,6 +595,114 @@ static mt_recloc* mt_find(mt_file* f, const char* rel, mt_recloc** last)
     return hit;
 }
 
+/* offsets of the directory records that pass the reader's plausibility checks (MatchFile.cpp:275-299) */
+static int mt_list(mt_file* f, int* off, int cap)
+{
+    int n = 0;
+    char* p = f->def;
+    for (int i = 0; i < f->h.file_count && n < cap; ++i) {
+        mt_recloc* rp = (mt_recloc*)p;
+        if (rp->read_loc <= 0 || rp->block_size == 0 || rp->extra_size > MT_MAX_PATH ||
+            rp->fcount > 1000000 || rp->fcount < 0)
+            break;
+        off[n++] = (int)(p - f->def);
+        p += sizeof(mt_recloc) + rp->extra_size;
+    }
+    return n;
+}
+
+#define MT_MAX_RECORDS 65536
+
+/* MatchFile::MoveRecordToEnd (MatchFile.cpp:422-453).  Returns the moved record at its new place. */
+static mt_recloc* mt_move_record_to_end(mt_file* f, int i)
+{
+    int* off = (int*)malloc(sizeof(int) * MT_MAX_RECORDS);
+    int n = mt_list(f, off, MT_MAX_RECORDS);
+    if (i >= n - 1 || i < 0 || n < 2) {
+        free(off);
+        return NULL;
+    }
+    int loc1 = off[i], loc2 = off[i + 1], len = loc2 - loc1;                            /* :428-430 */
+    char* temp = (char*)malloc((size_t)len);
+    memcpy(temp, f->def + loc1, (size_t)len);                                           /* :432 */
+    memmove(f->def + loc1, f->def + loc2, (size_t)(f->h.definition_size - loc2));       /* :433 */
+    memcpy(f->def + f->h.definition_size - len, temp, (size_t)len);                     /* :435 */
+    free(temp);
+    n = mt_list(f, off, MT_MAX_RECORDS);                                                /* :437 */
+    if (i == 0) {
+        f->h.definition_buf += len;                                                     /* :441 */
+        f->def = (char*)realloc(f->def, (size_t)f->h.definition_buf);
+        memset(f->def + f->h.definition_buf - len, 0, (size_t)len);
+    } else {
+        ((mt_recloc*)(f->def + off[i - 1]))->trash_size += len;                         /* :445 */
+    }
+    mt_recloc* last = (mt_recloc*)(f->def + off[n - 1]);
+    mt_recloc* prev = (mt_recloc*)(f->def + off[n - 2]);
+    last->read_loc = prev->read_loc + prev->block_size;                                 /* :449-450 */
+    free(off);
+    return last;
+}
+
+/* The full-directory branch of MatchFile::AddImageMatch (MatchFile.cpp:494-560): the data blocks that sit
+ * where the doubled directory will be move to the end of the file, their directory records rotate to the
+ * end of the directory.  Returns the new record (name, sizes not yet set beyond what :542-548 sets). */
+static mt_recloc* mt_grow_and_add(mt_file* f, const char* rel, int elen, int rlen)
+{
+    int* off = (int*)malloc(sizeof(int) * MT_MAX_RECORDS);
+    int n = mt_list(f, off, MT_MAX_RECORDS);
+    int extra_needed = rlen + f->h.definition_buf;                                      /* :497 */
+    int move = 0, extra_space = 0;
+    while (extra_space < extra_needed && move < n) {                                    /* :502-507 */
+        mt_recloc* loc = (mt_recloc*)(f->def + off[move]);
+        extra_space += loc->block_size + loc->trash_size;
+        move++;
+    }
+    if (extra_space < extra_needed || n == 0) {   /* the reference would run off its record list here */
+        free(off);
+        return NULL;
+    }
+    char* buf = (char*)malloc((size_t)extra_space);
+    memset(buf, 0, (size_t)extra_space);
+    mt_recloc* first = (mt_recloc*)(f->def + off[0]);
+    lseek(f->fd, first->read_loc, SEEK_SET);                                            /* :513-514 */
+    read_all(f->fd, buf, (size_t)extra_space);
+    mt_recloc* back = (mt_recloc*)(f->def + off[n - 1]);
+    int wloc = back->read_loc + back->block_size;                                       /* :517 */
+    char* pbuf = buf;
+    for (int i = 0; i < move; ++i) {                                                    /* :519-527 */
+        mt_recloc* loc = (mt_recloc*)(f->def + off[i]);
+        lseek(f->fd, wloc, SEEK_SET);
+        write_all(f->fd, pbuf, (size_t)loc->block_size);
+        pbuf += loc->block_size + loc->trash_size;
+        loc->read_loc = wloc;
+        wloc += loc->block_size;
+        loc->trash_size = 0;
+    }
+    free(buf);
+    if (move < n) {                                                                     /* :530-537 */
+        int definition_move = off[move];
+        char* temp = (char*)malloc((size_t)f->h.definition_size);
+        memcpy(temp, f->def, (size_t)f->h.definition_size);
+        memcpy(f->def, temp + definition_move, (size_t)(f->h.definition_size - definition_move));
+        memcpy(f->def + f->h.definition_size - definition_move, temp, (size_t)definition_move);
+        free(temp);
+    }
+    int old_buf = f->h.definition_buf;
+    f->h.definition_buf = f->h.definition_buf * 2 + rlen;                               /* :538-539 */
+    f->def = (char*)realloc(f->def, (size_t)f->h.definition_buf);
+    memset(f->def + old_buf, 0, (size_t)(f->h.definition_buf - old_buf));
+    mt_recloc* rec = (mt_recloc*)(f->def + f->h.definition_size);                       /* :542-548 */
+    rec->read_loc = wloc;
+    rec->trash_size = 0;
+    rec->block_size = 0;
+    rec->extra_size = elen;
+    strcpy(rec->file_name, rel);
+    f->h.definition_size += rlen;                                                       /* :556-557 */
+    f->h.file_count++;
+    free(off);
+    return rec;
+}
+
 static int mt_write_one(const char* image, const char* other, int fc_other, int nm,
                         const int32_t* row_this, const int32_t* row_other, int reservation)
 {
@@ -615,30 +723,46 @@ static int mt_write_one(const char* image, const char* other, int fc_other, int 
             f.h.definition_size = rlen;
             loc = (mt_recloc*)f.def;
             loc->read_loc = (int32_t)sizeof(mt_header) + f.h.definition_buf;
+            strcpy(loc->file_name, rel);
+            loc->extra_size = elen;
+            loc->trash_size = 0;
         } else if (f.h.definition_size + rlen < f.h.definition_buf) { /* :483-493 */
             loc = (mt_recloc*)(f.def + f.h.definition_size);
             loc->read_loc = last->read_loc + last->block_size;
             f.h.definition_size += rlen;
             f.h.file_count++;
-        } else {
-            mt_close(&f);
-            return -2; /* directory regrow (MatchFile.cpp:494-560) is not restated */
-        }
-        strcpy(loc->file_name, rel);
-        loc->extra_size = elen;
-        loc->trash_size = 0;
-        loc->block_size = bs;
-    } else if (loc == last) { /* :781-786 */
-        loc->block_size = bs;
-    } else {
-        int bsmin = (int)sizeof(mt_record) + (nm > 0 ? nm : 0) * (int)sizeof(int32_t) * 4;
-        if (bsmin > loc->block_size) {
-            if (bsmin > loc->block_size + loc->trash_size) { mt_close(&f); return -2; }
-            loc->block_size += loc->trash_size;
+            strcpy(loc->file_name, rel);
+            loc->extra_size = elen;
             loc->trash_size = 0;
+        } else { /* :494-560 */
+            loc = mt_grow_and_add(&f, rel, elen, rlen);
+            if (!loc) { mt_close(&f); return -2; }
+        }
+        loc->fcount = fc_other;
+        loc->block_size = bs; /* a new record is the last one: :781-786 */
+    } else {
+        loc->fcount = fc_other; /* :777 */
+        if (loc == last) { /* :781-786 */
+            loc->block_size = bs;
+        } else {
+            int bsmin = (int)sizeof(mt_record) + (nm > 0 ? nm : 0) * (int)sizeof(int32_t) * 4;
+            if (bsmin > loc->block_size) {
+                if (bsmin > loc->block_size + loc->trash_size) { /* :792-798 */
+                    int* off = (int*)malloc(sizeof(int) * MT_MAX_RECORDS);
+                    int n = mt_list(&f, off, MT_MAX_RECORDS), idx = -1;
+                    for (int i = 0; i < n; ++i)
+                        if ((mt_recloc*)(f.def + off[i]) == loc) idx = i;
+                    free(off);
+                    loc = mt_move_record_to_end(&f, idx);
+                    if (!loc) { mt_close(&f); return -2; }
+                    loc->block_size = bs;
+                } else { /* :801-802 */
+                    loc->block_size += loc->trash_size;
+                    loc->trash_size = 0;
+                }
+            }
         }
     }
-    loc->fcount = fc_other;
     /* :834-852 header + directory */
     lseek(f.fd, 0, SEEK_SET);
     write_all(f.fd, &f.h, sizeof f.h);

@@ -172,6 +172,72 @@ def test_mat_bytes_match_oracle(tmp_path):
     assert len(host.get_pmatch(str(d1 / str(a)), str(d1 / str(b)), fc[b] + 1)[0]) == 0
 
 
+def test_mat_outgrown_blocks_and_full_directory_match_oracle(tmp_path):
+    """Re-writes that outgrow a block in the middle of a file and the block of record 0 (the record moves to the
+    end: MatchFile::MoveRecordToEnd, MatchFile.cpp:422-453, with its bookkeeping of trash_size and
+    definition_buf), a re-write that fits block + trash, and more partners than the directory holds
+    (AddImageMatch's regrow, :494-560): product and oracle leave the same bytes, and every record reads back."""
+    rng = np.random.default_rng(31)
+    d1, d2 = tmp_path / "p", tmp_path / "o"
+    d1.mkdir()
+    d2.mkdir()
+    n = 8
+    fc = [300 + 10 * k for k in range(n)]
+    truth = {}
+
+    def put(a, b, nm):
+        ia = np.sort(rng.choice(fc[a], nm, replace=False)).astype(np.int32)
+        ib = rng.integers(0, fc[b], nm).astype(np.int32)
+        host.write_pmatch(str(d1 / ("i%d" % a)), str(d1 / ("i%d" % b)), fc[a], fc[b], ia, ib)
+        assert orc.mat_write_pmatch(str(d2 / ("i%d" % a)), str(d2 / ("i%d" % b)), fc[a], fc[b], ia, ib) == 0
+        truth[(a, b)] = (ia, ib)
+
+    for b in range(1, n):
+        put(0, b, 10 + b)                 # file i0: records for i1 .. i7, in that order
+    put(0, 3, 200)                        # outgrows a block in the middle: record i3 moves behind i7
+    put(0, 1, 250)                        # outgrows the block of record 0
+    put(0, 5, 12)                         # smaller: stays where it is
+    put(0, 4, 40)                         # needs more than its block, fits block + trash? (else it moves)
+    put(0, 2, 300)
+    put(0, 3, 260)                        # the moved record again, now not the last one
+    for a in range(n):
+        x = (d1 / ("i%d.mat" % a)).read_bytes()
+        y = (d2 / ("i%d.mat" % a)).read_bytes()
+        assert x == y, "i%d.mat differs" % a
+    for (a, b), (ia, ib) in truth.items():
+        ga, gb = host.get_pmatch(str(d1 / ("i%d" % a)), str(d1 / ("i%d" % b)), fc[b])
+        np.testing.assert_array_equal(ga, ia)
+        np.testing.assert_array_equal(gb, ib)
+        oa, ob = orc.mat_get_pmatch(str(d2 / ("i%d" % b)), str(d2 / ("i%d" % a)), fc[a])
+        np.testing.assert_array_equal(oa, ib)
+        np.testing.assert_array_equal(ob, ia)
+    hdr = np.frombuffer((d1 / "i0.mat").read_bytes()[:20], np.int32)
+    assert hdr[3] > 5680                  # definition_buf grew by the length of record 0's directory entry
+
+    # a full directory: 300 partners with a reservation of 20 records (5680 bytes)
+    hub1, hub2 = str(tmp_path / "p" / "hub"), str(tmp_path / "o" / "hub")
+    lists = []
+    for k in range(300):
+        nm = int(rng.integers(1, 30))
+        ia = np.sort(rng.choice(100, nm, replace=False)).astype(np.int32)
+        ib = rng.integers(0, 40 + k, nm).astype(np.int32)
+        lists.append((ia, ib))
+        host.write_pmatch(hub1, str(tmp_path / "p" / ("img%03d" % k)), 100, 40 + k, ia, ib)
+        assert orc.mat_write_pmatch(hub2, str(tmp_path / "o" / ("img%03d" % k)), 100, 40 + k, ia, ib) == 0
+    # and blocks outgrown after the directory has been rotated
+    for k in (0, 150, 7):
+        ia = np.arange(40, dtype=np.int32)
+        ib = np.arange(40, dtype=np.int32)[::-1].copy()
+        lists[k] = (ia, ib)
+        host.write_pmatch(hub1, str(tmp_path / "p" / ("img%03d" % k)), 100, 40 + k, ia, ib)
+        assert orc.mat_write_pmatch(hub2, str(tmp_path / "o" / ("img%03d" % k)), 100, 40 + k, ia, ib) == 0
+    assert open(hub1 + ".mat", "rb").read() == open(hub2 + ".mat", "rb").read()
+    for k in range(300):
+        ga, gb = host.get_pmatch(hub1, str(tmp_path / "p" / ("img%03d" % k)), 40 + k)
+        np.testing.assert_array_equal(ga, lists[k][0])
+        np.testing.assert_array_equal(gb, lists[k][1])
+
+
 def test_mat_first_file_size(tmp_path):
     a, b = str(tmp_path / "0"), str(tmp_path / "1")
     host.write_pmatch(a, b, 10, 12, [1, 4, 7], [0, 5, 9])

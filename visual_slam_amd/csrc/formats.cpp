@@ -602,7 +602,10 @@ public:
         }
         return true;
     }
-    // moves record i behind the last one (MatchFile.cpp:422-453); data is re-written by the caller
+    // Moves the directory record i behind the last one; the caller re-writes its data at the new place
+    // (MatchFile.cpp:422-453, bookkeeping included: the predecessor's trash_size grows by the LENGTH OF THE
+    // DIRECTORY RECORD, not by the size of the vacated block, and when record 0 moves the header's
+    // definition_buf grows by that length instead; the moved record keeps its own trash_size).
     void move_to_end(int i)
     {
         if (i < 0 || i >= (int)recs_.size() - 1) return;
@@ -611,6 +614,12 @@ public:
         dir_.erase(dir_.begin() + a, dir_.begin() + b);
         dir_.insert(dir_.begin() + (hdr_.definition_size - len), tmp.begin(), tmp.end());
         index_directory();
+        if (i == 0) {
+            hdr_.definition_buf += (int32_t)len;
+            dir_.resize((size_t)hdr_.definition_buf, 0);
+        } else {
+            rec(i - 1)->trash_size += (int32_t)len;
+        }
         MatRecLoc* last = rec(recs_.size() - 1);
         const MatRecLoc* prev = rec(recs_.size() - 2);
         last->read_loc = prev->read_loc + prev->block_size;
@@ -707,6 +716,7 @@ int mat_put(MatFile& mf, const std::string& other, int fc_other, int nm, const i
     if (idx < 0) idx = mf.add(rel, reservation);
     if (idx < 0) return VSM_EIO;
     MatRecLoc* loc = mf.rec(idx);
+    loc->fcount = fc_other;
     // MatchFile.cpp:781-805
     const int fresh_size = (int)sizeof(MatRecord) + std::max(nm, 8) * (int)sizeof(int32_t) * 6;
     if (loc->block_size == 0 || idx == (int)mf.count() - 1) {
@@ -715,20 +725,16 @@ int mat_put(MatFile& mf, const std::string& other, int fc_other, int nm, const i
         const int need = (int)sizeof(MatRecord) + std::max(nm, 0) * (int)sizeof(int32_t) * 4;
         if (need > loc->block_size) {
             if (need > loc->block_size + loc->trash_size) {
-                // the old block becomes unused space in front of its successor
-                if (idx > 0) mf.rec(idx - 1)->trash_size += loc->block_size + loc->trash_size;
-                mf.move_to_end(idx);
+                mf.move_to_end(idx);   // the vacated block stays in the file as dead bytes
                 idx = (int)mf.count() - 1;
                 loc = mf.rec(idx);
                 loc->block_size = fresh_size;
-                loc->trash_size = 0;
             } else {
                 loc->block_size += loc->trash_size;
                 loc->trash_size = 0;
             }
         }
     }
-    loc->fcount = fc_other;
     if (flush_dir && !mf.flush_directory()) return VSM_EIO;
     // MatchFile.cpp:813-831
     MatRecord rec;
