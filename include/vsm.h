@@ -215,6 +215,20 @@ long long vsm_verify_matches(vsm_ctx* ctx, const int32_t* xy_pairs, int npairs, 
                              float* F, int32_t* nf, int64_t* in_offsets, int32_t* in_idx0,
                              int32_t* in_idx1, long long cap);
 
+/* Relative pose of each pair from its fundamental matrix and the two cameras' intrinsics: what the
+ * reference's estimate_pose gets from cv2.findEssentialMat + cv2.recoverPose (models/utils.py:288-312)
+ * and what a match record's TwoViewGeometry holds as NE, R, T (MatchFile.h:68-83).  E = K1^T F K0 is
+ * decomposed into its four (R, +-t) candidates; the one with most inlier matches in front of both
+ * cameras wins.  cameras[npairs][8] = fx, fy, cx, cy of the pair's first image, then of its second;
+ * F[npairs][9] and the inlier lists as vsm_verify_matches returned them.  Out: R[npairs][9] (row-major),
+ * T[npairs][3] with X1 = R X0 + T for a point X0 in the first camera's frame and |T| = 1 (the scale is
+ * not observable), ne[npairs] = matches in front of both cameras (0: no pose, R = T = 0).  The reference
+ * holds no estimator of its own (OpenCV's is not installed here): the procedure is this library's,
+ * deterministic, and stated step by step beside the kernel.  Returns the number of pairs with a pose. */
+int vsm_recover_pose(vsm_ctx* ctx, const int32_t* xy_pairs, int npairs, const float* cameras, const float* F,
+                     const int64_t* in_offsets, const int32_t* in_idx0, const int32_t* in_idx1,
+                     float* R, float* T, int32_t* ne);
+
 /* ---- measurement ----------------------------------------------------------------- */
 /* With timing on, the distance kernel of each submission is bracketed by HIP events on
  * the context's stream; vsm_last_kernel_ms returns the last bracket (synchronises). */
@@ -327,6 +341,18 @@ int vsm_mat_get_match_count(const char* image, const char* other, int* nm, int* 
  * that is too small returns VSM_EUNSUPPORTED. */
 int vsm_mat_write_fmatch(const char* image1, const char* image2, int nf, const int32_t* idx1,
                          const int32_t* idx2, const float* F);
+/* MatchFile::WriteIMatch (MatchFile.cpp:643-748) with the whole two-view geometry: NF, F and the inlier
+ * lists as vsm_mat_write_fmatch writes them, plus NE, R, T and the two focal lengths F1, F2
+ * (MatchFile.h:68-83).  The second image's file gets the exchanged view, as SetGeometryR does
+ * (MatchFile.h:121-141): F and R transposed, T = -R^T T, F1 and F2 swapped.  ne = 0 writes no pose. */
+int vsm_mat_write_ematch(const char* image1, const char* image2, int nf, const int32_t* idx1, const int32_t* idx2,
+                         const float* F, int ne, const float* R, const float* T, float f1, float f2);
+int vsm_mat_writer_put_ematch(vsm_matwriter* w, const char* image1, const char* image2, int nf,
+                              const int32_t* idx1, const int32_t* idx2, const float* F, int ne, const float* R,
+                              const float* T, float f1, float f2);
+/* The pose fields of the record of `other` in `image`'s file, as stored there: *ne, R[9], T[3],
+ * f12[2] = F1, F2.  Returns NM of the record (0 when absent or rejected by the reference's checks). */
+int vsm_mat_get_pose(const char* image, const char* other, int fc_other, int* ne, float* R, float* T, float* f12);
 /* MatchFile::GetIMatch / GetIMatchR (MatchFile.cpp:961-1084): F[9], *nf and up to cap inlier pairs;
  * returns NM of the record (0 when absent or rejected by the reference's checks). */
 /* The same through the cached writer that vsm_mat_writer_open returns. */

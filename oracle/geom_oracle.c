@@ -364,3 +364,139 @@ int oracle_geom_pair(const float* xy0, int n0, const float* xy1, int n1, const i
     free(Fs);
     return nf;
 }
+
+/* ---- relative pose from F and the intrinsics ------------------------------------------------
+ * The library's stated procedure, restated (the reference gets R, t from OpenCV's findEssentialMat +
+ * recoverPose, models/utils.py:288-312: PARITY UNPINNED, as for F): E = K1^T F K0; Jacobi on E^T E;
+ * v1, v2 = eigenvectors of the two largest eigenvalues, v3 = v1 x v2; u1 = E v1 / |E v1|, u2 = E v2
+ * orthogonalised against u1 and normalised, u3 = u1 x u2; candidates (U W V^T, +-u3), (U W^T V^T, +-u3);
+ * the one with most matches in front of both cameras, earliest of equals.  All double, fixed order. */
+typedef struct {
+    double R[2][9];
+    double t[3];
+    int ok;
+} pose_cand;
+
+static void pose_candidates(const float* Fin, const float* cam, pose_cand* pc)
+{
+    const double fx0 = cam[0], fy0 = cam[1], cx0 = cam[2], cy0 = cam[3];
+    const double fx1 = cam[4], fy1 = cam[5], cx1 = cam[6], cy1 = cam[7];
+    double M[9], E[9], S[9], V[9];
+    for (int i = 0; i < 3; ++i) {
+        const double f0 = (double)Fin[3 * i], f1 = (double)Fin[3 * i + 1], f2 = (double)Fin[3 * i + 2];
+        M[3 * i + 0] = f0 * fx0;
+        M[3 * i + 1] = f1 * fy0;
+        M[3 * i + 2] = (f0 * cx0 + f1 * cy0) + f2;
+    }
+    for (int j = 0; j < 3; ++j) {
+        E[j] = fx1 * M[j];
+        E[3 + j] = fy1 * M[3 + j];
+        E[6 + j] = (cx1 * M[j] + cy1 * M[3 + j]) + M[6 + j];
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            S[3 * i + j] = (E[i] * E[j] + E[3 + i] * E[3 + j]) + E[6 + i] * E[6 + j];
+            V[3 * i + j] = i == j ? 1.0 : 0.0;
+        }
+    static const int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
+    for (int sweep = 0; sweep < 6; ++sweep)
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = P[pq], q = Q[pq];
+            const double apq = S[3 * p + q];
+            if (apq == 0.0) continue;
+            const double theta = (S[3 * q + q] - S[3 * p + p]) / (2.0 * apq);
+            const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+            for (int k = 0; k < 3; ++k) {
+                const double a = S[3 * k + p], b = S[3 * k + q];
+                S[3 * k + p] = c * a - s * b;
+                S[3 * k + q] = s * a + c * b;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double a = S[3 * p + k], b = S[3 * q + k];
+                S[3 * p + k] = c * a - s * b;
+                S[3 * q + k] = s * a + c * b;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double a = V[3 * k + p], b = V[3 * k + q];
+                V[3 * k + p] = c * a - s * b;
+                V[3 * k + q] = s * a + c * b;
+            }
+        }
+    int im = 0;
+    if (S[4] < S[0]) im = 1;
+    if (S[8] < S[3 * im + im]) im = 2;
+    int ia = im == 0 ? 1 : 0, ib = im == 2 ? 1 : 2;
+    if (S[3 * ib + ib] > S[3 * ia + ia]) { const int t = ia; ia = ib; ib = t; }
+    const double v1[3] = {V[ia], V[3 + ia], V[6 + ia]}, v2[3] = {V[ib], V[3 + ib], V[6 + ib]};
+    const double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+    double a[3], b[3];
+    for (int r = 0; r < 3; ++r) {
+        a[r] = (E[3 * r] * v1[0] + E[3 * r + 1] * v1[1]) + E[3 * r + 2] * v1[2];
+        b[r] = (E[3 * r] * v2[0] + E[3 * r + 1] * v2[1]) + E[3 * r + 2] * v2[2];
+    }
+    const double na = sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+    pc->ok = 0;
+    if (!(na > 0.0) || !(na < 1e300)) return;
+    const double u1[3] = {a[0] / na, a[1] / na, a[2] / na};
+    const double d = (b[0] * u1[0] + b[1] * u1[1]) + b[2] * u1[2];
+    b[0] -= d * u1[0]; b[1] -= d * u1[1]; b[2] -= d * u1[2];
+    const double nb = sqrt((b[0] * b[0] + b[1] * b[1]) + b[2] * b[2]);
+    if (!(nb > 0.0)) return;
+    const double u2[3] = {b[0] / nb, b[1] / nb, b[2] / nb};
+    const double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            pc->R[0][3 * r + c] = (u2[r] * v1[c] - u1[r] * v2[c]) + u3[r] * v3[c];
+            pc->R[1][3 * r + c] = (u1[r] * v2[c] - u2[r] * v1[c]) + u3[r] * v3[c];
+        }
+    pc->t[0] = u3[0]; pc->t[1] = u3[1]; pc->t[2] = u3[2];
+    pc->ok = 1;
+}
+
+static unsigned pose_front_bits(const pose_cand* pc, const float* cam, const float* p)
+{
+    const double x0 = ((double)p[0] - (double)cam[2]) / (double)cam[0], y0 = ((double)p[1] - (double)cam[3]) / (double)cam[1];
+    const double x1 = ((double)p[2] - (double)cam[6]) / (double)cam[4], y1 = ((double)p[3] - (double)cam[7]) / (double)cam[5];
+    const double e0 = y1 * pc->t[2] - pc->t[1], e1 = pc->t[0] - x1 * pc->t[2], e2 = x1 * pc->t[1] - y1 * pc->t[0];
+    unsigned bits = 0;
+    for (int k = 0; k < 2; ++k) {
+        const double* R = pc->R[k];
+        const double r0 = (R[0] * x0 + R[1] * y0) + R[2], r1 = (R[3] * x0 + R[4] * y0) + R[5], r2 = (R[6] * x0 + R[7] * y0) + R[8];
+        const double c0 = y1 * r2 - r1, c1 = r0 - x1 * r2, c2 = x1 * r1 - y1 * r0;
+        const double cc = (c0 * c0 + c1 * c1) + c2 * c2;
+        if (!(cc > 0.0)) continue;
+        const double g = (e0 * c0 + e1 * c1) + e2 * c2;
+        const double lp = -g / cc, lm = g / cc;
+        if (lp > 0.0 && lp * r2 + pc->t[2] > 0.0) bits |= 1u << (2 * k);
+        if (lm > 0.0 && lm * r2 - pc->t[2] > 0.0) bits |= 1u << (2 * k + 1);
+    }
+    return bits;
+}
+
+/* cam: fx, fy, cx, cy of image 0 then image 1.  idx0 / idx1: the n inlier matches.  Returns NE. */
+int oracle_pose_pair(const float* xy0, int n0, const float* xy1, int n1, const int32_t* idx0, const int32_t* idx1, int n,
+                     const float* F, const float* cam, float* R, float* T)
+{
+    for (int j = 0; j < 9; ++j) R[j] = 0.0f;
+    for (int j = 0; j < 3; ++j) T[j] = 0.0f;
+    pose_cand pc;
+    pose_candidates(F, cam, &pc);
+    if (!pc.ok) return 0;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int m = 0; m < n; ++m) {
+        const int i = idx0[m], j = idx1[m];
+        if (i < 0 || i >= n0 || j < 0 || j >= n1) continue;
+        const float p[4] = {xy0[2 * i], xy0[2 * i + 1], xy1[2 * j], xy1[2 * j + 1]};
+        const unsigned bits = pose_front_bits(&pc, cam, p);
+        for (int k = 0; k < 4; ++k) cnt[k] += (bits >> k) & 1u;
+    }
+    int best = 0;
+    for (int k = 1; k < 4; ++k)
+        if (cnt[k] > cnt[best]) best = k;
+    if (cnt[best] <= 0) return 0;
+    for (int j = 0; j < 9; ++j) R[j] = (float)pc.R[best >> 1][j];
+    for (int j = 0; j < 3; ++j) T[j] = (float)((best & 1) ? -pc.t[j] : pc.t[j]);
+    return cnt[best];
+}
+

@@ -210,6 +210,23 @@ def geom_pair(xy0, xy1, idx0, idx1, max_sampson=2.0, hypotheses=256, seed=0, pai
     return F.reshape(3, 3), in0[:nf], in1[:nf]
 
 
+def pose_pair(xy0, xy1, idx0, idx1, F, cam):
+    """The library's stated pose recovery for one pair, in scalar C: (R [3, 3], T [3], NE)."""
+    xy0 = np.ascontiguousarray(xy0, np.float32)
+    xy1 = np.ascontiguousarray(xy1, np.float32)
+    idx0 = np.ascontiguousarray(idx0, np.int32)
+    idx1 = np.ascontiguousarray(idx1, np.int32)
+    F = np.ascontiguousarray(F, np.float32).reshape(9)
+    cam = np.ascontiguousarray(cam, np.float32).reshape(8)
+    R, T = np.zeros(9, np.float32), np.zeros(3, np.float32)
+    fn = lib().oracle_pose_pair
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_void_p]
+    ne = fn(_p(xy0), len(xy0), _p(xy1), len(xy1), _p(idx0), _p(idx1), len(idx0), _p(F), _p(cam), _p(R), _p(T))
+    return R.reshape(3, 3), T, ne
+
+
 def shortlist(words_per_image, nwords, topk):
     """Pair shortlist from per-image word assignments; returns (pairs [n, 2], scores [nimg, nimg])."""
     nimg = len(words_per_image)

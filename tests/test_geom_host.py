@@ -134,3 +134,70 @@ def test_cached_writer_leaves_the_same_files(tmp_path):
     a, b, p0, p1, sel, F = recs[3]
     nm, Fg, r0, r1 = vsm.get_imatch(str(d2 / str(a)), str(d2 / str(b)), fc[b])
     assert nm == len(p0) or len(p0) == 0
+
+
+def _cams(K):
+    return np.asarray([K[0, 0], K[1, 1], K[0, 2], K[1, 2]] * 2, np.float32)
+
+
+def test_oracle_recovers_planted_pose():
+    """F by RANSAC, then E = K1^T F K0 decomposed: the rotation within a fraction of a degree and the
+    translation direction within a few degrees of the planted ones; every inlier in front of both cameras."""
+    for seed in (3, 5, 8):
+        xy0, xy1, i0, i1, true, _, K, R, t = synth.two_view(600, seed=seed, inlier_fraction=0.6, noise=0.4, with_pose=True)
+        F, in0, in1 = orc.geom_pair(xy0, xy1, i0, i1, max_sampson=2.0, hypotheses=512, seed=9)
+        Rg, Tg, ne = orc.pose_pair(xy0, xy1, in0, in1, F, _cams(K))
+        assert ne >= 0.95 * len(in0)
+        Rg = Rg.astype(np.float64)
+        assert abs(np.linalg.det(Rg) - 1.0) < 1e-5 and np.allclose(Rg @ Rg.T, np.eye(3), atol=1e-5)
+        ang = np.degrees(np.arccos(np.clip((np.trace(Rg.T @ R) - 1.0) / 2.0, -1.0, 1.0)))
+        assert ang < 0.5
+        assert abs(np.linalg.norm(Tg) - 1.0) < 1e-5
+        tdir = np.degrees(np.arccos(np.clip(np.dot(Tg, t / np.linalg.norm(t)), -1.0, 1.0)))
+        assert tdir < 5.0
+    # no inliers, a zero matrix: no pose
+    Rg, Tg, ne = orc.pose_pair(xy0, xy1, in0[:0], in1[:0], F, _cams(K))
+    assert ne == 0 and not Rg.any() and not Tg.any()
+    Rg, Tg, ne = orc.pose_pair(xy0, xy1, in0, in1, np.zeros(9, np.float32), _cams(K))
+    assert ne == 0 and not Rg.any()
+
+
+def test_pose_records_round_trip(tmp_path):
+    """NE, R, T, F1, F2 of TwoViewGeometry through vsm_mat_write_ematch / vsm_mat_get_pose: the first image's
+    file holds them as given, the second image's file the exchanged view (R^T, -R^T T, focal lengths
+    swapped: SetGeometryR, MatchFile.h:121-141); the inlier records stay what write_fmatch writes."""
+    rng = np.random.default_rng(21)
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    p0 = np.sort(rng.choice(500, 60, replace=False)).astype(np.int32)
+    p1 = rng.choice(400, 60, replace=False).astype(np.int32)
+    vsm.write_pmatch(a, b, 500, 400, p0, p1)
+    sel = np.arange(0, 60, 2)
+    F = rng.standard_normal((3, 3)).astype(np.float32)
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    R = (q * np.sign(np.linalg.det(q))).astype(np.float32)
+    T = rng.standard_normal(3).astype(np.float32)
+    T /= np.linalg.norm(T)
+    assert vsm.write_ematch(a, b, p0[sel], p1[sel], F, 27, R, T, 1200.0, 900.0) == 1
+    nm, ne, Ra, Ta, f12 = vsm.get_pose(a, b, 400)
+    assert (nm, ne, f12) == (60, 27, (1200.0, 900.0))
+    np.testing.assert_array_equal(Ra, R)
+    np.testing.assert_array_equal(Ta, T)
+    nm, ne, Rb, Tb, f12 = vsm.get_pose(b, a, 500)
+    assert (nm, ne, f12) == (60, 27, (900.0, 1200.0))
+    np.testing.assert_array_equal(Rb, R.T)
+    np.testing.assert_allclose(Tb, -(R.T.astype(np.float64) @ T), rtol=0, atol=1e-6)
+    # exchanging the view twice gives the pose back
+    np.testing.assert_allclose(-(Rb.T.astype(np.float64) @ Tb), T, rtol=0, atol=1e-6)
+    nm_a, Fa, r0, r1 = vsm.get_imatch(a, b, 400)
+    np.testing.assert_array_equal(Fa, F)
+    np.testing.assert_array_equal(r0, p0[sel])
+    np.testing.assert_array_equal(r1, p1[sel])
+    # record bytes: NF, NE at the head of the geometry, R after F
+    raw = open(a + ".mat", "rb").read()
+    loc = struct.unpack("<i", raw[20 + 4:20 + 8])[0]
+    assert struct.unpack("<ii", raw[loc + 8:loc + 16]) == (30, 27)
+    assert np.frombuffer(raw[loc + 8 + 16 + 36:loc + 8 + 16 + 72], np.float32).tolist() == R.reshape(9).tolist()
+    # a pose without an F is refused, ne = 0 writes none
+    assert vsm.lib().vsm_mat_write_ematch(a.encode(), b.encode(), 0, None, None, None, 5, None, None, 1.0, 1.0) < 0
+    assert vsm.write_ematch(a, b, p0[sel], p1[sel], F, 0, R, T, 1.0, 2.0) == 1
+    assert vsm.get_pose(a, b, 400)[1] == 0 and not vsm.get_pose(a, b, 400)[2].any()

@@ -124,6 +124,37 @@ def test_cli_verifies_matches_on_the_device(tmp_path):
     assert "geometric verification: %d pairs" % len(put) in res.stderr and kept > 1000
 
 
+def test_cli_writes_the_relative_pose(tmp_path):
+    """--camera: NE, R, T of every verified pair in the .mat records, equal to the oracle's pose from the F and
+    the inlier lists of the same run; the partner's file holds the exchanged view."""
+    nimg, n = 3, 500
+    kps, dess = synth.multi_view(nimg, n, seed=35)
+    for i in range(nimg):
+        loc = np.zeros((n, 5), np.float32)
+        loc[:, :2] = kps[i]
+        loc[:, 3] = 1.0
+        host.write_sift(str(tmp_path / ("%d.sift" % i)), loc, dess[i])
+    out, inl = str(tmp_path / "matching.txt"), str(tmp_path / "inliers.txt")
+    cmd = [CLI, "--sift-dir", str(tmp_path), "--num", str(nimg), "--out", out, "--mat", "--verify", "1.5",
+           "--samples", "300", "--seed", "5", "--inlier-out", inl, "--camera", "1200,1200,800,600"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert "relative pose: 3 pairs" in res.stderr
+    cam = np.asarray([1200, 1200, 800, 600] * 2, np.float32)
+    for (a0, a1, v0, v1) in _read_records(inl):
+        ia, ib = int(a0.split(".")[0]), int(a1.split(".")[0])
+        nm, F, r0, r1 = host.get_imatch(str(tmp_path / str(ia)), str(tmp_path / str(ib)), n)
+        oR, oT, one = orc.pose_pair(kps[ia], kps[ib], v0, v1, F, cam)
+        nm2, ne, R, T, f12 = host.get_pose(str(tmp_path / str(ia)), str(tmp_path / str(ib)), n)
+        assert nm2 == nm and ne == one and one > 100 and f12 == (1200.0, 1200.0)
+        np.testing.assert_array_equal(R, oR)
+        np.testing.assert_array_equal(T, oT)
+        _, ne_b, Rb, Tb, _ = host.get_pose(str(tmp_path / str(ib)), str(tmp_path / str(ia)), n)
+        assert ne_b == one
+        np.testing.assert_array_equal(Rb, oR.T)
+        np.testing.assert_allclose(Tb, -(oR.T.astype(np.float64) @ oT), atol=1e-6)
+
+
 def test_sharded_verification_equals_the_unsharded_run(tmp_path):
     """The RANSAC samples are keyed by a pair's position in the whole pair list, so cutting the list into
     shards and submissions in another way gives the same inlier file byte for byte."""

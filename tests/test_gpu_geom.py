@@ -125,3 +125,51 @@ def test_estimate_fundamental_helper(matcher):
     np.testing.assert_array_equal(F, oF)
     np.testing.assert_array_equal(np.nonzero(mask)[0], o0)
     assert vsm.estimate_fundamental(matcher, xy0[:7], xy1[:7], 1.5) is None
+
+
+def test_pose_bit_exact_and_close_to_planted(matcher):
+    """vsm_recover_pose against the oracle bit for bit (R, T in float32, the count), over pairs of many
+    sizes, different cameras per image, a pair without inliers and a zero matrix; and within half a degree
+    (rotation) / a few degrees (translation direction) of the planted pose where the scene has one."""
+    sizes = [600, 0, 40, 1500, 9, 300]
+    scenes = [synth.two_view(max(n, 1), seed=200 + k, inlier_fraction=0.7, noise=0.4, with_pose=True) for k, n in enumerate(sizes)]
+    ids = [(matcher.upload_xy(s[0]), matcher.upload_xy(s[1])) for s in scenes]
+    lists = [(s[2][:n], s[3][:n]) for s, n in zip(scenes, sizes)]
+    off = np.zeros(len(sizes) + 1, np.int64)
+    off[1:] = np.cumsum(sizes)
+    F, nf, in_off, g0, g1 = matcher.verify_matches(ids, off, np.concatenate([l[0] for l in lists]),
+                                                   np.concatenate([l[1] for l in lists]), max_sampson=2.0, hypotheses=512, seed=5)
+    cams = np.zeros((len(sizes), 8), np.float32)
+    for p, s in enumerate(scenes):
+        K = s[6]
+        cams[p] = [K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 0], K[1, 1], K[0, 2], K[1, 2]]
+    cams[3, 4:] *= 1.0          # (same camera twice in the synthetic scenes)
+    F2 = F.copy()
+    F2[5] = 0.0                 # a zero matrix has no decomposition
+    R, T, ne = matcher.recover_pose(ids, cams, F2, in_off, g0, g1)
+    for p, s in enumerate(scenes):
+        oR, oT, one = orc.pose_pair(s[0], s[1], g0[in_off[p]:in_off[p + 1]], g1[in_off[p]:in_off[p + 1]], F2[p], cams[p])
+        np.testing.assert_array_equal(R[p], oR, err_msg="pair %d" % p)
+        np.testing.assert_array_equal(T[p], oT, err_msg="pair %d" % p)
+        assert ne[p] == one
+    assert ne[1] == 0 and ne[5] == 0 and not R[5].any()
+    for p in (0, 3):
+        Rt, tt = scenes[p][7], scenes[p][8]
+        ang = np.degrees(np.arccos(np.clip((np.trace(R[p].astype(np.float64).T @ Rt) - 1.0) / 2.0, -1.0, 1.0)))
+        tdir = np.degrees(np.arccos(np.clip(np.dot(T[p], tt / np.linalg.norm(tt)), -1.0, 1.0)))
+        assert ang < 0.5 and tdir < 5.0 and ne[p] >= 0.95 * nf[p]
+    for a, b in ids:
+        matcher.release(a)
+        matcher.release(b)
+
+
+def test_estimate_pose_in_the_reference_calling_style(matcher):
+    """host.estimate_pose(kpts0, kpts1, K0, K1, thresh) -> (R, t, mask), None for fewer than five matches
+    (models/utils.py:288-312)."""
+    xy0, xy1, i0, i1, true, _, K, Rt, tt = synth.two_view(500, seed=31, inlier_fraction=0.7, noise=0.4, with_pose=True)
+    k0, k1 = xy0[i0], xy1[i1]
+    assert vsm.estimate_pose(matcher, k0[:4], k1[:4], K, K, 2.0) is None
+    R, t, mask = vsm.estimate_pose(matcher, k0, k1, K, K, 2.0, samples=512, seed=3)
+    assert mask.dtype == bool and len(mask) == 500 and (mask & true).sum() >= 0.95 * true.sum()
+    ang = np.degrees(np.arccos(np.clip((np.trace(R.astype(np.float64).T @ Rt) - 1.0) / 2.0, -1.0, 1.0)))
+    assert ang < 0.5

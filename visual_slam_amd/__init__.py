@@ -35,6 +35,9 @@ from .host import (  # noqa: F401
     get_pmatch_r,
     get_match_count,
     write_fmatch,
+    write_ematch,
+    get_pose,
+    estimate_pose,
     get_imatch,
     get_imatch_r,
     estimate_fundamental,
@@ -49,6 +52,6 @@ __all__ = [
     "generate_imagePairs", "generate_exhaustive_pairs", "get_list_matching_pairs",
     "save_matching_sfm", "save_feature_locations", "read_feature_locations",
     "read_sift", "write_sift", "write_pmatch", "get_pmatch", "get_pmatch_r", "get_match_count",
-    "write_fmatch", "get_imatch", "get_imatch_r", "estimate_fundamental",
+    "write_fmatch", "write_ematch", "get_pose", "estimate_pose", "get_imatch", "get_imatch_r", "estimate_fundamental",
     "nearest_embed", "mutual_nn_match",
 ]

@@ -113,6 +113,13 @@ SIGNATURES = {
     "vsm_verify_matches": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_longlong]),
+    "vsm_recover_pose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsm_mat_write_ematch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
+    "vsm_mat_writer_put_ematch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
+    "vsm_mat_get_pose": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsm_mat_write_fmatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsm_mat_writer_put_fmatch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsm_mat_get_imatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.POINTER(C.c_int),
@@ -412,6 +419,25 @@ class Matcher:
                                              C.byref(g), _ptr(F), _ptr(nf), _ptr(in_off), _ptr(in0), _ptr(in1), cap)
         got = self._check(got)
         return F, nf, in_off, in0[:got], in1[:got]
+
+    def recover_pose(self, xy_pairs, cameras, F, in_offsets, in_idx0, in_idx1):
+        """Relative pose per pair from its fundamental matrix, the two cameras' intrinsics (cameras
+        [npairs, 8] = fx, fy, cx, cy of the first image, then of the second) and its inlier matches.
+        Returns (R [npairs, 3, 3], T [npairs, 3], ne [npairs]): X1 = R X0 + T, |T| = 1, ne = matches in front
+        of both cameras (0: no pose)."""
+        xy_pairs = np.ascontiguousarray(xy_pairs, dtype=np.int32).reshape(-1, 2)
+        npairs = xy_pairs.shape[0]
+        cameras = np.ascontiguousarray(cameras, np.float32).reshape(npairs, 8)
+        F = np.ascontiguousarray(F, np.float32).reshape(npairs, 9)
+        in_offsets = np.ascontiguousarray(in_offsets, np.int64)
+        in_idx0 = np.ascontiguousarray(in_idx0, np.int32)
+        in_idx1 = np.ascontiguousarray(in_idx1, np.int32)
+        R = np.zeros((npairs, 3, 3), np.float32)
+        T = np.zeros((npairs, 3), np.float32)
+        ne = np.zeros(npairs, np.int32)
+        self._check(self._l.vsm_recover_pose(self._h, _ptr(xy_pairs), npairs, _ptr(cameras), _ptr(F), _ptr(in_offsets),
+                                             _ptr(in_idx0), _ptr(in_idx1), _ptr(R), _ptr(T), _ptr(ne)))
+        return R, T, ne
 
     # ---- measurement --------------------------------------------------------------------
     def set_scratch_budget(self, nbytes):

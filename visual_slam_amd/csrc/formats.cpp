@@ -896,8 +896,15 @@ namespace {
 // have room, which every record written by WritePMatch has (block = 184 + max(NM, 8) * 24 bytes against
 // 188 + (NM + NF) * 8 needed, NF <= NM); the reference's re-allocation branch (:690-719) moves the
 // directory entry without the putative lists and is not reproduced.
+struct MatPose {   // NE, R, T, F1, F2 of TwoViewGeometry (MatchFile.h:68-83); ne = 0: none
+    int ne = 0;
+    const float* R = nullptr;
+    const float* T = nullptr;
+    float f1 = 0.0f, f2 = 0.0f;
+};
+
 int mat_put_inliers(MatFile& mf, const std::string& other, bool reverse, int nf,
-                    const int32_t* row_a, const int32_t* row_b, const float* F)
+                    const int32_t* row_a, const int32_t* row_b, const float* F, const MatPose& pose = MatPose())
 {
     const int idx = mf.find(relative_name(mf.image(), other));
     if (idx < 0) return 0;
@@ -914,6 +921,25 @@ int mat_put_inliers(MatFile& mf, const std::string& other, bool reverse, int nf,
     if (nf > 0)
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) rec.tvg.F[i][j] = reverse ? F[3 * j + i] : F[3 * i + j];   // SetGeometryR transposes
+    // SetGeometry / SetGeometryR (MatchFile.h:121-161): NE and the focal lengths always, R and T only
+    // beside an F; the exchanged view stores R^T and -R^T T, each component summed in the reference's order
+    rec.tvg.NE = pose.ne;
+    rec.tvg.F1 = reverse ? pose.f2 : pose.f1;
+    rec.tvg.F2 = reverse ? pose.f1 : pose.f2;
+    if (nf > 0 && pose.ne > 0) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) rec.tvg.R[i][j] = reverse ? pose.R[3 * j + i] : pose.R[3 * i + j];
+        for (int i = 0; i < 3; ++i) {
+            if (reverse) {
+                float t = -rec.tvg.R[i][0] * pose.T[0];
+                t = t - rec.tvg.R[i][1] * pose.T[1];
+                t = t - rec.tvg.R[i][2] * pose.T[2];
+                rec.tvg.T[i] = t;
+            } else {
+                rec.tvg.T[i] = pose.T[i];
+            }
+        }
+    }
     if (!mf.write_at((off_t)loc->read_loc + 4, &rec, sizeof rec)) return VSM_EIO;
     if (nf > 0) {
         const off_t at = (off_t)loc->read_loc + 4 + (off_t)sizeof rec + (off_t)nm * 8;
@@ -953,6 +979,74 @@ extern "C" int vsm_mat_writer_put_fmatch(vsm_matwriter* w, const char* image1, c
     int rb = b ? mat_put_inliers(*b, image1, true, nf, idx1, idx2, F) : VSM_EIO;
     if (rb < 0) return rb;
     return ra == 1 && rb == 1 ? 1 : 0;
+}
+
+static int pose_args_bad(int nf, int ne, const float* R, const float* T)
+{
+    return ne < 0 || (ne > 0 && (!R || !T || nf <= 0));
+}
+
+extern "C" int vsm_mat_write_ematch(const char* image1, const char* image2, int nf, const int32_t* idx1,
+                                    const int32_t* idx2, const float* F, int ne, const float* R, const float* T,
+                                    float f1, float f2)
+{
+    if (!image1 || !image2 || !image1[0] || !image2[0] || nf < 0 || (nf > 0 && (!idx1 || !idx2 || !F))) return VSM_EINVAL;
+    if (pose_args_bad(nf, ne, R, T)) return VSM_EINVAL;
+    if (strlen(image1) + 5 > (size_t)kMaxPath || strlen(image2) + 5 > (size_t)kMaxPath) return VSM_EINVAL;
+    MatPose pose;
+    pose.ne = ne; pose.R = R; pose.T = T; pose.f1 = f1; pose.f2 = f2;
+    MatFile m1, m2;
+    if (!m1.open(image1, true)) return VSM_EIO;
+    const int a = mat_put_inliers(m1, image2, false, nf, idx1, idx2, F, pose);
+    if (a < 0) return a;
+    if (!m2.open(image2, true)) return VSM_EIO;
+    const int b = mat_put_inliers(m2, image1, true, nf, idx1, idx2, F, pose);
+    if (b < 0) return b;
+    return a == 1 && b == 1 ? 1 : 0;
+}
+
+extern "C" int vsm_mat_writer_put_ematch(vsm_matwriter* w, const char* image1, const char* image2, int nf,
+                                         const int32_t* idx1, const int32_t* idx2, const float* F, int ne,
+                                         const float* R, const float* T, float f1, float f2)
+{
+    if (!w || !image1 || !image2 || !image1[0] || !image2[0] || nf < 0 || (nf > 0 && (!idx1 || !idx2 || !F))) return VSM_EINVAL;
+    if (pose_args_bad(nf, ne, R, T)) return VSM_EINVAL;
+    if (w->failed) return VSM_EIO;
+    MatPose pose;
+    pose.ne = ne; pose.R = R; pose.T = T; pose.f1 = f1; pose.f2 = f2;
+    MatFile* a = w->get(image1);
+    int ra = a ? mat_put_inliers(*a, image2, false, nf, idx1, idx2, F, pose) : VSM_EIO;
+    if (ra < 0) return ra;
+    MatFile* b = w->get(image2);
+    int rb = b ? mat_put_inliers(*b, image1, true, nf, idx1, idx2, F, pose) : VSM_EIO;
+    if (rb < 0) return rb;
+    return ra == 1 && rb == 1 ? 1 : 0;
+}
+
+extern "C" int vsm_mat_get_pose(const char* image, const char* other, int fc_other, int* ne, float* R, float* T,
+                                float* f12)
+{
+    if (ne) *ne = 0;
+    if (R) memset(R, 0, 9 * sizeof(float));
+    if (T) memset(T, 0, 3 * sizeof(float));
+    if (f12) f12[0] = f12[1] = 0.0f;
+    if (!image || !other) return 0;
+    MatFile mf;
+    if (!mf.open(image, false)) return 0;
+    const int idx = mf.find(relative_name(image, other));
+    if (idx < 0) return 0;
+    const MatRecLoc* loc = mf.rec(idx);
+    if (loc->fcount != fc_other) return 0;   // MatchFile.cpp:975
+    int32_t nm = 0;
+    MatRecord rec;
+    if (mf.read_at(loc->read_loc, &nm, 4) != 4) return 0;
+    if (mf.read_at((off_t)loc->read_loc + 4, &rec, sizeof rec) != (ssize_t)sizeof rec) return 0;
+    if (nm > loc->fcount || nm <= 0 || rec.version != kRecVersion || rec.tvg.NF > loc->fcount) return 0;   // :988, :995
+    if (ne) *ne = rec.tvg.NE;
+    if (R) memcpy(R, rec.tvg.R, 9 * sizeof(float));
+    if (T) memcpy(T, rec.tvg.T, 3 * sizeof(float));
+    if (f12) { f12[0] = rec.tvg.F1; f12[1] = rec.tvg.F2; }
+    return nm;
 }
 
 static int mat_get_inliers(const char* image, const char* other, int fc_other, bool reverse, float* F, int* nf,

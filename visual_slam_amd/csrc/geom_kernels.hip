@@ -536,6 +536,160 @@ void geom_emit_kernel(const GeomPair* __restrict__ pairs, const float4* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------
+// relative pose from a fundamental matrix and the two cameras' intrinsics
+// ---------------------------------------------------------------------------------
+// What cv2.findEssentialMat + cv2.recoverPose give the reference's estimate_pose
+// (Others/SuperPoint_data/models/utils.py:288-312) and what a match record's TwoViewGeometry holds as
+// NE, R, T (MatchFile.h:68-83): E = K1^T F K0; its singular vectors (Jacobi on E^T E, the two
+// leading left vectors by Gram-Schmidt on E v1, E v2, third vectors as cross products so that both bases
+// are right-handed); the four decompositions (U W V^T, +-u3), (U W^T V^T, +-u3); the one with most
+// inlier matches in front of both cameras (earliest of equals in that order).  All in double, every
+// operation written out in a fixed order so that the scalar checker reproduces the bits.
+// Convention: X1 = R X0 + T for a point X0 in the first camera's frame, |T| = 1.
+struct PoseCandidates {
+    double R[2][9];
+    double t[3];
+    bool ok;
+};
+
+__device__ void pose_candidates(const float* __restrict__ Fin, const float* __restrict__ cam, PoseCandidates& pc)
+{
+    const double fx0 = cam[0], fy0 = cam[1], cx0 = cam[2], cy0 = cam[3];
+    const double fx1 = cam[4], fy1 = cam[5], cx1 = cam[6], cy1 = cam[7];
+    double M[9], E[9], S[9], V[9];
+    for (int i = 0; i < 3; ++i) {
+        const double f0 = (double)Fin[3 * i], f1 = (double)Fin[3 * i + 1], f2 = (double)Fin[3 * i + 2];
+        M[3 * i + 0] = f0 * fx0;
+        M[3 * i + 1] = f1 * fy0;
+        M[3 * i + 2] = (f0 * cx0 + f1 * cy0) + f2;
+    }
+    for (int j = 0; j < 3; ++j) {
+        E[j] = fx1 * M[j];
+        E[3 + j] = fy1 * M[3 + j];
+        E[6 + j] = (cx1 * M[j] + cy1 * M[3 + j]) + M[6 + j];
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            S[3 * i + j] = (E[i] * E[j] + E[3 + i] * E[3 + j]) + E[6 + i] * E[6 + j];
+            V[3 * i + j] = i == j ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 6; ++sweep) {
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+            const double apq = S[3 * p + q];
+            if (apq == 0.0) continue;
+            const double theta = (S[3 * q + q] - S[3 * p + p]) / (2.0 * apq);
+            const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+            for (int k = 0; k < 3; ++k) {
+                const double skp = S[3 * k + p], skq = S[3 * k + q];
+                S[3 * k + p] = c * skp - s * skq;
+                S[3 * k + q] = s * skp + c * skq;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double spk = S[3 * p + k], sqk = S[3 * q + k];
+                S[3 * p + k] = c * spk - s * sqk;
+                S[3 * q + k] = s * spk + c * sqk;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double vkp = V[3 * k + p], vkq = V[3 * k + q];
+                V[3 * k + p] = c * vkp - s * vkq;
+                V[3 * k + q] = s * vkp + c * vkq;
+            }
+        }
+    }
+    int im = 0;
+    if (S[4] < S[0]) im = 1;
+    if (S[8] < S[3 * im + im]) im = 2;
+    int ia = im == 0 ? 1 : 0, ib = im == 2 ? 1 : 2;
+    if (S[3 * ib + ib] > S[3 * ia + ia]) { const int t = ia; ia = ib; ib = t; }
+    const double v1[3] = {V[ia], V[3 + ia], V[6 + ia]}, v2[3] = {V[ib], V[3 + ib], V[6 + ib]};
+    const double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+    double a[3], b[3];
+    for (int r = 0; r < 3; ++r) {
+        a[r] = (E[3 * r] * v1[0] + E[3 * r + 1] * v1[1]) + E[3 * r + 2] * v1[2];
+        b[r] = (E[3 * r] * v2[0] + E[3 * r + 1] * v2[1]) + E[3 * r + 2] * v2[2];
+    }
+    const double na = sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+    pc.ok = false;
+    if (!(na > 0.0) || !(na < 1e300)) return;
+    const double u1[3] = {a[0] / na, a[1] / na, a[2] / na};
+    const double d = (b[0] * u1[0] + b[1] * u1[1]) + b[2] * u1[2];
+    b[0] -= d * u1[0]; b[1] -= d * u1[1]; b[2] -= d * u1[2];
+    const double nb = sqrt((b[0] * b[0] + b[1] * b[1]) + b[2] * b[2]);
+    if (!(nb > 0.0)) return;
+    const double u2[3] = {b[0] / nb, b[1] / nb, b[2] / nb};
+    const double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            pc.R[0][3 * r + c] = (u2[r] * v1[c] - u1[r] * v2[c]) + u3[r] * v3[c];   // U W V^T
+            pc.R[1][3 * r + c] = (u1[r] * v2[c] - u2[r] * v1[c]) + u3[r] * v3[c];   // U W^T V^T
+        }
+    pc.t[0] = u3[0]; pc.t[1] = u3[1]; pc.t[2] = u3[2];
+    pc.ok = true;
+}
+
+// which of the four decompositions put the match (x0, y0) <-> (x1, y1) in front of both cameras: bit
+// 2 * rot + (translation negated)
+__device__ __forceinline__ unsigned pose_front_bits(const PoseCandidates& pc, const float* __restrict__ cam, const float4 p)
+{
+    const double x0 = ((double)p.x - (double)cam[2]) / (double)cam[0], y0 = ((double)p.y - (double)cam[3]) / (double)cam[1];
+    const double x1 = ((double)p.z - (double)cam[6]) / (double)cam[4], y1 = ((double)p.w - (double)cam[7]) / (double)cam[5];
+    // e = x1^ x t (x1^ = (x1, y1, 1))
+    const double e0 = y1 * pc.t[2] - pc.t[1], e1 = pc.t[0] - x1 * pc.t[2], e2 = x1 * pc.t[1] - y1 * pc.t[0];
+    unsigned bits = 0;
+    for (int k = 0; k < 2; ++k) {
+        const double* R = pc.R[k];
+        const double r0 = (R[0] * x0 + R[1] * y0) + R[2], r1 = (R[3] * x0 + R[4] * y0) + R[5], r2 = (R[6] * x0 + R[7] * y0) + R[8];
+        const double c0 = y1 * r2 - r1, c1 = r0 - x1 * r2, c2 = x1 * r1 - y1 * r0;   // x1^ x R x0^
+        const double cc = (c0 * c0 + c1 * c1) + c2 * c2;
+        if (!(cc > 0.0)) continue;
+        const double g = (e0 * c0 + e1 * c1) + e2 * c2;
+        const double lp = -g / cc, lm = g / cc;            // depth in the first camera for +t and -t
+        if (lp > 0.0 && lp * r2 + pc.t[2] > 0.0) bits |= 1u << (2 * k);
+        if (lm > 0.0 && lm * r2 - pc.t[2] > 0.0) bits |= 1u << (2 * k + 1);
+    }
+    return bits;
+}
+
+// one wave per pair
+__global__ __launch_bounds__(64)
+void geom_pose_kernel(const GeomPair* __restrict__ pairs, const float* __restrict__ cams, const float* __restrict__ Fs,
+                      const int32_t* __restrict__ idx0, const int32_t* __restrict__ idx1,
+                      float* __restrict__ Rout, float* __restrict__ Tout, int32_t* __restrict__ ne)
+{
+    const GeomPair gp = pairs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const float* cam = cams + 8 * (size_t)blockIdx.x;
+    const float* F = Fs + 9 * (size_t)blockIdx.x;
+    PoseCandidates pc;
+    pose_candidates(F, cam, pc);
+    int cnt[4] = {0, 0, 0, 0};
+    if (pc.ok) {
+        for (int m = lane; m < gp.n; m += 64) {
+            const int i = idx0[gp.off + m], j = idx1[gp.off + m];
+            if (i < 0 || i >= gp.n0 || j < 0 || j >= gp.n1) continue;
+            const float4 p = make_float4(gp.xy0[2 * i], gp.xy0[2 * i + 1], gp.xy1[2 * j], gp.xy1[2 * j + 1]);
+            const unsigned bits = pose_front_bits(pc, cam, p);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cnt[k] += (bits >> k) & 1u;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (int d = 32; d > 0; d >>= 1) cnt[k] += __shfl_xor(cnt[k], d);
+    int best = 0;
+    for (int k = 1; k < 4; ++k)
+        if (cnt[k] > cnt[best]) best = k;
+    if (lane == 0) {
+        const bool have = pc.ok && cnt[best] > 0;
+        ne[blockIdx.x] = have ? cnt[best] : 0;
+        for (int j = 0; j < 9; ++j) Rout[9 * (size_t)blockIdx.x + j] = have ? (float)pc.R[best >> 1][j] : 0.0f;
+        for (int j = 0; j < 3; ++j) Tout[3 * (size_t)blockIdx.x + j] = have ? (float)((best & 1) ? -pc.t[j] : pc.t[j]) : 0.0f;
+    }
+}
+
 __global__ void geom_pack_pairs_kernel(const GeomPair* __restrict__ gp, int npairs, SiftPair* __restrict__ sp)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -547,6 +701,14 @@ __global__ void geom_pack_pairs_kernel(const GeomPair* __restrict__ gp, int npai
 }
 
 }  // namespace
+
+void launch_geom_pose(const GeomPair* pairs, int npairs, const float* cams, const float* Fs, const int32_t* idx0,
+                      const int32_t* idx1, float* R, float* T, int32_t* ne, hipStream_t s)
+{
+    if (npairs <= 0) return;
+    hipLaunchKernelGGL(geom_pose_kernel, dim3(npairs), dim3(64), 0, s, pairs, cams, Fs, idx0, idx1, R, T, ne);
+}
+
 
 size_t geom_lds_bytes() { return (size_t)72 * kGeomThreads * sizeof(double); }
 

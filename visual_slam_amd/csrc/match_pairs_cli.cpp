@@ -39,6 +39,8 @@ struct Options {
     unsigned seed = 0;
     int min_inliers = 0;
     std::string inlier_out;       // match txt of the verified matches
+    bool have_camera = false;     // --camera: relative pose per verified pair
+    float camera[4] = {0, 0, 0, 0};   // fx, fy, cx, cy (one camera for the whole collection)
 };
 
 void usage()
@@ -66,6 +68,8 @@ void usage()
             "                        Sampson-distance threshold); with --mat the inlier records are written too\n"
             "  --samples N           RANSAC samples per pair (default 256); --seed S; --min-inliers K\n"
             "  --inlier-out FILE     match txt of the verified matches (same format as --out)\n"
+            "  --camera FX,FY,CX,CY  intrinsics of the collection's camera: with --verify, the relative pose of every\n"
+            "                        verified pair (E = K^T F K decomposed); with --mat it goes into the records (NE, R, T)\n"
             "  --name-ext EXT        image-name suffix in the match txt (default .jpg)\n"
             "  --device N, --batch P (pairs per GPU submission, default 4096; two are in flight)\n"
             "  --shard R/W           match only the R-th of W contiguous slices of the pair list, cut at equal\n"
@@ -122,6 +126,15 @@ bool parse(int argc, char** argv, Options& o)
         else if (a == "--seed") { if (!(v = next("--seed"))) return false; o.seed = (unsigned)strtoul(v, nullptr, 10); }
         else if (a == "--min-inliers") { if (!(v = next("--min-inliers"))) return false; o.min_inliers = atoi(v); }
         else if (a == "--inlier-out") { if (!(v = next("--inlier-out"))) return false; o.inlier_out = v; }
+        else if (a == "--camera") {
+            if (!(v = next("--camera"))) return false;
+            if (sscanf(v, "%f,%f,%f,%f", &o.camera[0], &o.camera[1], &o.camera[2], &o.camera[3]) != 4 ||
+                !(o.camera[0] > 0.0f) || !(o.camera[1] > 0.0f)) {
+                fprintf(stderr, "--camera takes FX,FY,CX,CY with positive focal lengths\n");
+                return false;
+            }
+            o.have_camera = true;
+        }
         else if (a == "--name-ext") { if (!(v = next("--name-ext"))) return false; o.name_ext = v; }
         else if (a == "--device") { if (!(v = next("--device"))) return false; o.device = atoi(v); }
         else if (a == "--batch") { if (!(v = next("--batch"))) return false; o.batch = atoi(v); }
@@ -138,6 +151,10 @@ bool parse(int argc, char** argv, Options& o)
         // every slice would update the records of the same <image>.mat files, and the writer keeps their
         // directories in memory until it closes
         fprintf(stderr, "--mat cannot be combined with --shard: write the .mat records from one process\n");
+        return false;
+    }
+    if (o.have_camera && !(o.verify > 0.0f)) {
+        fprintf(stderr, "--camera needs --verify\n");
         return false;
     }
     if (!o.inlier_out.empty() && !(o.verify > 0.0f)) {
@@ -374,6 +391,9 @@ int main(int argc, char** argv)
         std::vector<float> F;
         std::vector<int32_t> nf, in0, in1;
         std::vector<int64_t> in_off;
+        // relative pose (--camera)
+        std::vector<float> R, T, cams;
+        std::vector<int32_t> ne;
     } batches[2];
     std::mutex mu;
     std::condition_variable cv;
@@ -421,7 +441,11 @@ int main(int argc, char** argv)
                     }
                     if (o.write_mat && !write_failed) {
                         const std::string p0 = o.sift_dir + "/" + std::to_string(ia), p1 = o.sift_dir + "/" + std::to_string(ib);
-                        if (vsm_mat_writer_put_fmatch(mw, p0.c_str(), p1.c_str(), nin, q0, q1, b.F.data() + (size_t)k * 9) < 0) {
+                        const int rc = o.have_camera
+                            ? vsm_mat_writer_put_ematch(mw, p0.c_str(), p1.c_str(), nin, q0, q1, b.F.data() + (size_t)k * 9, b.ne[k],
+                                                        b.R.data() + (size_t)k * 9, b.T.data() + (size_t)k * 3, o.camera[0], o.camera[0])
+                            : vsm_mat_writer_put_fmatch(mw, p0.c_str(), p1.c_str(), nin, q0, q1, b.F.data() + (size_t)k * 9);
+                        if (rc < 0) {
                             write_error = "cannot write inlier record for pair " + std::to_string(ia) + " " + std::to_string(ib);
                             write_failed.store(true, std::memory_order_release);
                         }
@@ -439,7 +463,7 @@ int main(int argc, char** argv)
     // GPU side: submission k + 1 is queued before the lists of submission k are collected, so the
     // device never waits for this thread or for the writer
     std::vector<int32_t> ids, xy_ids;
-    long long total = 0, total_inliers = 0, pairs_with_geometry = 0;
+    long long total = 0, total_inliers = 0, pairs_with_geometry = 0, pairs_with_pose = 0;
     bool gpu_failed = false;
     const long long nbatches = (npairs + o.batch - 1) / o.batch;
     auto submit = [&](long long k) {
@@ -507,6 +531,22 @@ int main(int argc, char** argv)
             }
             total_inliers += gin;
             for (int q = 0; q < take; ++q) pairs_with_geometry += b.nf[q] > 0;
+            if (o.have_camera) {
+                b.R.resize((size_t)take * 9);
+                b.T.resize((size_t)take * 3);
+                b.ne.resize((size_t)take);
+                b.cams.resize((size_t)take * 8);
+                for (int q = 0; q < take; ++q)
+                    for (int e = 0; e < 8; ++e) b.cams[(size_t)q * 8 + e] = o.camera[e & 3];
+                const int np = vsm_recover_pose(ctx, xy_ids.data(), take, b.cams.data(), b.F.data(), b.in_off.data(), b.in0.data(),
+                                                b.in1.data(), b.R.data(), b.T.data(), b.ne.data());
+                if (np < 0) {
+                    fprintf(stderr, "vsm_recover_pose: %s\n", vsm_last_error(ctx));
+                    gpu_failed = true;
+                    break;
+                }
+                pairs_with_pose += np;
+            }
         }
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -541,6 +581,7 @@ int main(int argc, char** argv)
     if (verify)
         fprintf(stderr, "geometric verification: %lld pairs with a fundamental matrix, %lld inlier matches\n",
                 pairs_with_geometry, total_inliers);
+    if (o.have_camera) fprintf(stderr, "relative pose: %lld pairs\n", pairs_with_pose);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     fprintf(stderr, "%d images, %lld pairs, %lld matches, %.3f s (%.0f pairs/s); reading + upload %.3f s, matching + writing %.3f s\n",
             o.num, npairs, total, secs, npairs / secs, load_secs, secs - load_secs);

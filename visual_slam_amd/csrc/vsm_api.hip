@@ -1564,6 +1564,71 @@ extern "C" int vsm_knn2(vsm_ctx* c, int set_q, int set_db, int metric,
     return A->n;
 }
 
+extern "C" int vsm_recover_pose(vsm_ctx* c, const int32_t* xy_pairs, int npairs, const float* cameras, const float* F,
+                                const int64_t* in_offsets, const int32_t* in_idx0, const int32_t* in_idx1,
+                                float* R, float* T, int32_t* ne)
+{
+    if (!c) return VSM_EINVAL;
+    if (npairs < 0 || (npairs > 0 && (!xy_pairs || !cameras || !F || !in_offsets || !R || !T || !ne)))
+        return fail(c, VSM_EINVAL, "bad argument");
+    if (npairs == 0) return 0;
+    const int64_t total = in_offsets[npairs];
+    if (in_offsets[0] != 0 || total < 0 || (total > 0 && (!in_idx0 || !in_idx1)))
+        return fail(c, VSM_EINVAL, "in_offsets must start at 0 and ascend, with the lists present");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<GeomPair> gp(npairs);
+    for (int p = 0; p < npairs; ++p) {
+        const DescSet* A = get_set(c, xy_pairs[2 * p]);
+        const DescSet* B = get_set(c, xy_pairs[2 * p + 1]);
+        if (!A || !B || A->kind != SET_XY || B->kind != SET_XY)
+            return fail(c, VSM_EINVAL, "pair %d does not name two keypoint sets", p);
+        const int64_t n = in_offsets[p + 1] - in_offsets[p];
+        if (n < 0 || n > INT32_MAX) return fail(c, VSM_EINVAL, "in_offsets must ascend (pair %d)", p);
+        for (int k = 0; k < 8; ++k)
+            if (k != 2 && k != 3 && k != 6 && k != 7 && !(cameras[8 * (size_t)p + k] > 0.0f))
+                return fail(c, VSM_EINVAL, "pair %d: focal lengths must be positive", p);
+        GeomPair& q = gp[p];
+        q.xy0 = static_cast<const float*>(A->frag);
+        q.xy1 = static_cast<const float*>(B->frag);
+        q.n0 = A->n; q.n1 = B->n;
+        q.n = (int32_t)n;
+        q.pad = 0;
+        q.off = in_offsets[p];
+    }
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t tot = (size_t)std::max<int64_t>(total, 1);
+    const size_t b_gp = up(sizeof(GeomPair) * npairs), b_cam = up((size_t)npairs * 32), b_F = up((size_t)npairs * 36);
+    const size_t b_idx = up(tot * 4), b_T = up((size_t)npairs * 12), b_ne = up((size_t)npairs * 4);
+    HIPCHK(c, c->d_geom.ensure(b_gp + b_cam + 2 * b_F + 2 * b_idx + b_T + b_ne));
+    char* w = c->d_geom.as<char>();
+    GeomPair* d_gp = reinterpret_cast<GeomPair*>(w); w += b_gp;
+    float* d_cam = reinterpret_cast<float*>(w); w += b_cam;
+    float* d_F = reinterpret_cast<float*>(w); w += b_F;
+    float* d_R = reinterpret_cast<float*>(w); w += b_F;
+    int32_t* d_i0 = reinterpret_cast<int32_t*>(w); w += b_idx;
+    int32_t* d_i1 = reinterpret_cast<int32_t*>(w); w += b_idx;
+    float* d_T = reinterpret_cast<float*>(w); w += b_T;
+    int32_t* d_ne = reinterpret_cast<int32_t*>(w); w += b_ne;
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // d_geom may still serve a queued verification
+    HIPCHK(c, hipMemcpyAsync(d_gp, gp.data(), sizeof(GeomPair) * npairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_cam, cameras, (size_t)npairs * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_F, F, (size_t)npairs * 36, hipMemcpyHostToDevice, c->stream));
+    if (total > 0) {
+        HIPCHK(c, hipMemcpyAsync(d_i0, in_idx0, (size_t)total * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_i1, in_idx1, (size_t)total * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    launch_geom_pose(d_gp, npairs, d_cam, d_F, d_i0, d_i1, d_R, d_T, d_ne, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(R, d_R, (size_t)npairs * 36, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(T, d_T, (size_t)npairs * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ne, d_ne, (size_t)npairs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // also: gp and the caller's arrays must outlive the copies
+    int with_pose = 0;
+    for (int p = 0; p < npairs; ++p) with_pose += ne[p] > 0;
+    return with_pose;
+}
+
+
 // ---------------------------------------------------------------------------------
 // geometric verification
 // ---------------------------------------------------------------------------------

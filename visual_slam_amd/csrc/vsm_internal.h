@@ -225,6 +225,13 @@ void launch_geom_verify(const GeomPair* pairs, int npairs, int max_matches, cons
                         float* Fout, int32_t* counts, int32_t* slot_i0, int32_t* slot_i1, SiftPair* pack_pairs,
                         hipStream_t s);
 
+// relative pose per pair from its fundamental matrix (Fs[npairs][9]), the two cameras' intrinsics
+// (cams[npairs][8] = fx, fy, cx, cy of image 0 then image 1) and its inlier matches (pairs[p].off / .n into
+// idx0 / idx1): R[npairs][9], T[npairs][3] (X1 = R X0 + T, |T| = 1), ne[npairs] = matches in front of both
+// cameras (0: no pose)
+void launch_geom_pose(const GeomPair* pairs, int npairs, const float* cams, const float* Fs, const int32_t* idx0,
+                      const int32_t* idx1, float* R, float* T, int32_t* ne, hipStream_t s);
+
 // ---- image-pair shortlist from a visual vocabulary ----------------------------------------
 // hist: [nimg][nwords] counts (zeroed by the caller); words / offsets: the tight nearest-row list of a
 // submission whose pair p is (image first_image + p, vocabulary) with every row accepted.

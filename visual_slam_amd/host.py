@@ -250,6 +250,62 @@ def write_fmatch(image1, image2, idx1, idx2, F):
     return rc
 
 
+def write_ematch(image1, image2, idx1, idx2, F, ne, R, T, f1, f2):
+    """MatchFile::WriteIMatch with the whole TwoViewGeometry (MatchFile.cpp:643-748, MatchFile.h:68-83): F and
+    the inlier lists as write_fmatch, plus NE, R, T and the focal lengths F1, F2; the second image's file gets
+    the exchanged view (SetGeometryR, MatchFile.h:121-141)."""
+    idx1 = np.ascontiguousarray(idx1, np.int32)
+    idx2 = np.ascontiguousarray(idx2, np.int32)
+    F = np.ascontiguousarray(F, np.float32).reshape(9)
+    R = np.ascontiguousarray(R, np.float32).reshape(9)
+    T = np.ascontiguousarray(T, np.float32).reshape(3)
+    rc = B.lib().vsm_mat_write_ematch(_b(image1), _b(image2), len(idx1), B._ptr(idx1), B._ptr(idx2), B._ptr(F), int(ne),
+                                      B._ptr(R), B._ptr(T), float(f1), float(f2))
+    if rc < 0:
+        raise IOError("vsm_mat_write_ematch failed (%d)" % rc)
+    return rc
+
+
+def get_pose(image, other, fc_other):
+    """The pose fields of a match record as stored in `image`'s file: (NM, NE, R [3, 3], T [3], (F1, F2))."""
+    import ctypes as C
+    R, T, f12 = np.zeros((3, 3), np.float32), np.zeros(3, np.float32), np.zeros(2, np.float32)
+    ne = C.c_int(0)
+    nm = B.lib().vsm_mat_get_pose(_b(image), _b(other), int(fc_other), C.byref(ne), B._ptr(R), B._ptr(T), B._ptr(f12))
+    return nm, ne.value, R, T, (float(f12[0]), float(f12[1]))
+
+
+def estimate_pose(matcher, kpts0, kpts1, K0, K1, thresh, samples=256, seed=0):
+    """The reference's estimate_pose (Others/SuperPoint_data/models/utils.py:288-312), same call and return
+    shape: matched keypoint arrays and the two 3 x 3 intrinsic matrices in, (R, t, inlier mask) out, None
+    with fewer than 5 matches or no pose.  `thresh` is in pixels (the reference divides it by the mean focal
+    length because it works on normalised coordinates; here the model is fitted in pixel coordinates).  The
+    estimator is this library's (fundamental matrix by RANSAC, then E = K1^T F K0 decomposed, the
+    decomposition with most inliers in front of both cameras), not OpenCV's five-point solver."""
+    kpts0 = np.ascontiguousarray(kpts0, np.float32)
+    kpts1 = np.ascontiguousarray(kpts1, np.float32)
+    if len(kpts0) < 5:
+        return None
+    got = estimate_fundamental(matcher, kpts0, kpts1, thresh, samples, seed)
+    if got is None:
+        return None
+    F, mask = got
+    sel = np.nonzero(mask)[0].astype(np.int32)
+    if len(sel) == 0:
+        return None
+    K0, K1 = np.asarray(K0, np.float64), np.asarray(K1, np.float64)
+    cams = np.asarray([K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], K1[0, 0], K1[1, 1], K1[0, 2], K1[1, 2]], np.float32)
+    s0, s1 = matcher.upload_xy(kpts0), matcher.upload_xy(kpts1)
+    try:
+        R, T, ne = matcher.recover_pose([[s0, s1]], cams, F, [0, len(sel)], sel, sel)
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)
+    if ne[0] <= 0:
+        return None
+    return R[0], T[0], mask
+
+
 def _get_imatch(fn, image, other, fc_other):
     import ctypes as C
     F = np.zeros((3, 3), np.float32)

@@ -48,11 +48,11 @@ def superpoint_pair(n0, n1, dim, seed, planted=0.25, sigma=0.05):
     return a, b
 
 
-def two_view(n, seed, inlier_fraction=0.6, noise=0.5, width=1600.0, height=1200.0):
+def two_view(n, seed, inlier_fraction=0.6, noise=0.5, width=1600.0, height=1200.0, with_pose=False):
     """Keypoints of two views of a random 3-D scene and n putative matches, the first
     round(inlier_fraction * n) of them true correspondences (pixel noise `noise`), the rest random
     pairings, then shuffled.  Returns (xy0 [n, 2], xy1 [n, 2], idx0, idx1, is_true, F) with
-    x1^T F x0 = 0 for the true ones."""
+    x1^T F x0 = 0 for the true ones; with_pose adds (K, R, t): X1 = R X0 + t in camera coordinates."""
     rng = np.random.default_rng(seed)
     f = 1200.0
     K = np.array([[f, 0, width / 2], [0, f, height / 2], [0, 0, 1.0]])
@@ -80,8 +80,9 @@ def two_view(n, seed, inlier_fraction=0.6, noise=0.5, width=1600.0, height=1200.
     tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
     Kinv = np.linalg.inv(K)
     F = Kinv.T @ tx @ R @ Kinv
-    return (xy0.astype(np.float32), xy1.astype(np.float32), idx0[order].astype(np.int32),
-            idx1[order].astype(np.int32), is_true[order], F / np.linalg.norm(F))
+    out = (xy0.astype(np.float32), xy1.astype(np.float32), idx0[order].astype(np.int32),
+           idx1[order].astype(np.int32), is_true[order], F / np.linalg.norm(F))
+    return out + (K, R, t) if with_pose else out
 
 
 def multi_view(nimages, n, seed, shared=0.6, desc_noise=4, pixel_noise=0.4):
