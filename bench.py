@@ -586,6 +586,19 @@ def run_geom_verify(args, torch, dist, world, rank):
     barrier_sync(torch, dist, world)
     dt = max_over_ranks(torch, dist, world, time.perf_counter() - t0)
     kms = float(np.mean(kernel_ms))
+    verified = None
+    if not args.no_verify:
+        # the first pairs of the last step against the scalar restatement: F bit for bit, the same inlier lists
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+        import oracle_lib as orc
+        ok = True
+        for p in range(0, npairs, npairs // 16):
+            sc = scenes[p % nscene]
+            oF, o0, o1 = orc.geom_pair(sc[4], sc[5], sc[2], sc[3], max_sampson=2.0, hypotheses=hyp, seed=7, pair_pos=p)
+            lo, hi = int(in_off[p]), int(in_off[p + 1])
+            ok = ok and np.array_equal(np.asarray(F[p], np.float32).reshape(-1).view(np.uint32), oF.reshape(-1).view(np.uint32))
+            ok = ok and np.array_equal(g0[lo:hi], o0) and np.array_equal(g1[lo:hi], o1)
+        verified = bool(sum_over_ranks(torch, dist, world, 0 if ok else 1) == 0)
     tests = float(npairs) * hyp * nmatch           # Sampson tests of one step
     flops = 33.0 * tests                           # 18 multiplies + 15 adds per test (15 of the pairs fused)
     achieved = flops / (kms * 1e-3) / 1e12
@@ -593,7 +606,7 @@ def run_geom_verify(args, torch, dist, world, rank):
         "metric": "image pairs verified/sec", "value": world * args.steps * npairs / dt, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "verified": verified,
         "config": {"workload": "fundamental-matrix RANSAC, %d pairs x %d matches, %d samples per pair per step"
                                % (npairs, nmatch, hyp),
                    "parallelism": "pair list sharded x%d" % world, "inliers_per_pair": float(np.mean(nf))},
@@ -648,13 +661,23 @@ def run_shortlist(args, torch, dist, world, rank):
     barrier_sync(torch, dist, world)
     dt = max_over_ranks(torch, dist, world, time.perf_counter() - t0)
     kms = float(np.mean(kernel_ms))
+    verified = None
+    if not args.no_verify:
+        # the whole list against the oracle: nearest word of every descriptor, then the integer scoring
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+        import oracle_lib as orc
+        vh = vocab.cpu().numpy()
+        words = [orc.knn2_u8(arena[i].cpu().numpy(), vh, host_threads()[0])[0] for i in range(nimg)]
+        opairs, _ = orc.shortlist(words, nwords, topk)
+        ok = np.array_equal(np.asarray(pairs, np.int32).reshape(-1, 2), opairs)
+        verified = bool(sum_over_ranks(torch, dist, world, 0 if ok else 1) == 0)
     ops = OPS_PER_EVAL_U8 * float(nimg) * nfeat * nwords    # the word assignment; the rest is < 1 % of the work
     achieved = ops / (kms * 1e-3) / 1e12
     out = {
         "metric": "images shortlisted/sec", "value": world * args.steps * nimg / dt, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "replicas",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic", "verified": verified,
         "config": {"workload": "vocabulary shortlist, %d images x %d SIFT-128 features, %d words, %d partners per image"
                                % (nimg, nfeat, nwords, topk),
                    "parallelism": "replicas only", "pairs_listed": int(len(pairs))},

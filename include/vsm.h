@@ -248,6 +248,27 @@ int vsm_sift_read(const char* path, float* locbuf, uint8_t* desbuf, int nmax,
 /* FeatureData::saveSIFTB2 (FeaturePoints.cpp:228-280).  Returns 1/0. */
 int vsm_sift_write(const char* path, const float* loc, int nloc_dim,
                    const uint8_t* des, int npoint);
+/* Lowe's ASCII keypoint file, FeatureData::ReadSIFTA (FeaturePoints.cpp:54-125): "npoint 128", then per
+ * feature "row col scale orientation" and 128 integers.  locbuf[n][5] receives (col + 0.5, row + 0.5, 0,
+ * scale, -orientation), desbuf the low 8 bits of every value.  NULL buffers query the count.  Returns the
+ * number of features in the file (0 on failure; only 128-value descriptors, as the binary reader). */
+int vsm_sift_read_ascii(const char* path, float* locbuf, uint8_t* desbuf, int nmax, int* npoint);
+/* FeatureData::saveSIFTA (FeaturePoints.cpp:205-226) for loc[n][5].  Returns the count or a negative code;
+ * writes nothing for an empty set, as there. */
+int vsm_sift_write_ascii(const char* path, const float* loc, const uint8_t* des, int npoint);
+/* FeatureData::SortSIFT (FeaturePoints.cpp:726-765) in place: descending scale (location column 3), features
+ * of equal scale in descending order of their old position (what its bubble sort of the reversed sequence
+ * leaves).  des may be NULL; order[npoint] (may be NULL) receives the old position of every new row. */
+int vsm_sift_sort_by_scale(float* loc, int nloc_dim, uint8_t* des, int npoint, int32_t* order);
+/* The in-memory part of FeatureData::ConvertA2B (FeaturePoints.cpp:655-695): if the first descriptor's norm
+ * is below 400, every descriptor is scaled to norm 512 and rounded, and location values 0 and 1 change
+ * places.  Returns 1 when it converted, 0 when the set was left alone.  An all-zero descriptor stays zero
+ * (the reference divides by zero there). */
+int vsm_sift_renormalise(float* loc, int nloc_dim, uint8_t* des, int npoint);
+/* ReadSIFTA + ConvertA2B (FeaturePoints.cpp:54-72, 655-710): the binary file takes the ASCII file's place
+ * ("x.sift.sift" -> "x.sift" and the ASCII file is removed; "x.sift" is overwritten; other names: nothing is
+ * written).  out_path[cap] (may be NULL) receives the name written.  Returns the feature count or < 0. */
+int vsm_sift_ascii_to_binary(const char* path, char* out_path, int cap);
 /* save_feature_locations (main.py:133-140) / ReadLocFromText (FeaturePoints.cpp:326-369). */
 int vsm_feature_txt_write(const char* path, const float* xy, int m);
 int vsm_feature_txt_read(const char* path, float* xy, int cap);

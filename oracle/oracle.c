@@ -456,6 +456,106 @@ int orc_sift_read(const char* path, float* loc, uint8_t* des, int nmax, int* nlo
     return np;
 }
 
+int orc_sift_read_ascii(const char* path, float* loc, uint8_t* des, int nmax)
+{
+    /* FeaturePoints.cpp:54-125 (ReadSIFTA, ReadFeatureDataA with locDim 4): the second number of a feature
+     * is x, the first y, both + 0.5; then z = 0, scale, the orientation negated */
+    FILE* fp = fopen(path, "r");
+    if (!fp) return 0;
+    int npt = 0, nd = 0;
+    if (fscanf(fp, "%d %d", &npt, &nd) != 2 || npt <= 0 || nd != DESC_DIM) { fclose(fp); return 0; }
+    for (int i = 0; i < npt && i < nmax; ++i) {
+        float* l = loc + (size_t)i * 5;
+        if (fscanf(fp, "%f", &l[1]) != 1 || fscanf(fp, "%f", &l[0]) != 1) { fclose(fp); return 0; }
+        l[0] += 0.5f;
+        l[1] += 0.5f;
+        l[2] = 0;
+        if (fscanf(fp, "%f", &l[3]) != 1 || fscanf(fp, "%f", &l[4]) != 1) { fclose(fp); return 0; }
+        l[4] = -l[4];
+        for (int j = 0; j < nd; ++j) {
+            unsigned int value;
+            if (fscanf(fp, "%u", &value) != 1) { fclose(fp); return 0; }
+            des[(size_t)i * DESC_DIM + j] = (uint8_t)value;
+        }
+    }
+    fclose(fp);
+    return npt;
+}
+
+long orc_sift_write_ascii(const char* path, const float* loc, const uint8_t* des, int n)
+{
+    /* FeaturePoints.cpp:205-226 (saveSIFTA); `ofstream << float` prints like %g */
+    if (n <= 0) return 0;
+    FILE* fp = fopen(path, "w");
+    if (!fp) return -1;
+    fprintf(fp, "%d %d\n", n, DESC_DIM);
+    for (int i = 0; i < n; ++i) {
+        const float* l = loc + (size_t)i * 5;
+        fprintf(fp, "%g %g %g %g\n", l[1], l[0], l[3], l[4]);
+        for (int k = 0; k < DESC_DIM; ++k) {
+            fprintf(fp, "%u ", (unsigned)des[(size_t)i * DESC_DIM + k]);
+            if ((k + 1) % 20 == 0) fprintf(fp, "\n");
+        }
+        fprintf(fp, "\n");
+    }
+    long total = ftell(fp);
+    fclose(fp);
+    return total;
+}
+
+void orc_sift_sort(float* loc, uint8_t* des, int nf, int32_t* order)
+{
+    /* FeaturePoints.cpp:726-765 (SortSIFT): bubble sort of the reversed sequence by scale, strict compare;
+     * then Points::reorder (points.h:413-436): new row i = old row order[i] */
+    if (nf == 0) return;
+    float* size = (float*)malloc(sizeof(float) * (size_t)nf);
+    for (int i = 0; i < nf; ++i) order[i] = nf - i - 1;
+    for (int i = 0; i < nf; ++i) size[i] = loc[5 * (nf - i - 1) + 3];
+    for (int i = 0; i < nf; ++i) {
+        int swapped = 0;
+        for (int j = nf - 1; j > i; --j) {
+            if (size[j] > size[j - 1]) {
+                float dt = size[j]; size[j] = size[j - 1]; size[j - 1] = dt;
+                int it = order[j]; order[j] = order[j - 1]; order[j - 1] = it;
+                swapped = 1;
+            }
+        }
+        if (!swapped) break;
+    }
+    float* l2 = (float*)malloc(sizeof(float) * 5 * (size_t)nf);
+    uint8_t* d2 = (uint8_t*)malloc((size_t)DESC_DIM * nf);
+    for (int i = 0; i < nf; ++i) {
+        memcpy(l2 + 5 * (size_t)i, loc + 5 * (size_t)order[i], sizeof(float) * 5);
+        memcpy(d2 + (size_t)DESC_DIM * i, des + (size_t)DESC_DIM * order[i], DESC_DIM);
+    }
+    memcpy(loc, l2, sizeof(float) * 5 * (size_t)nf);
+    memcpy(des, d2, (size_t)DESC_DIM * nf);
+    free(size); free(l2); free(d2);
+}
+
+int orc_sift_convert_a2b(float* loc, uint8_t* des, int n)
+{
+    /* FeaturePoints.cpp:655-695 (ConvertA2B before it saves).  An all-zero row would divide by zero there;
+     * it is left alone here. */
+    double normal = 0;
+    for (int i = 0; i < DESC_DIM; ++i) normal += des[i] * des[i];
+    normal = sqrt(normal);
+    if (!(normal < 400)) return 0;
+    for (int i = 0; i < n; ++i) {
+        uint8_t* d = des + (size_t)DESC_DIM * i;
+        normal = 0;
+        for (int j = 0; j < DESC_DIM; ++j) normal += d[j] * d[j];
+        if (normal == 0) continue;
+        normal = 512.0 / sqrt(normal);
+        for (int k = 0; k < DESC_DIM; ++k) d[k] = (uint8_t)(unsigned)floor(normal * d[k] + 0.5);
+    }
+    for (int j = 0; j < n; ++j) {
+        float* l = loc + 5 * (size_t)j;
+        float t = l[0]; l[0] = l[1]; l[1] = t;
+    }
+    return 1;
+}
+
 long orc_matchtxt_record(const char* name0, const char* name1, const int32_t* matches0, int n,
                          char* buf, size_t bufsz)
 {

@@ -162,6 +162,49 @@ def sift_read(path):
     return loc, des
 
 
+def sift_read_ascii(path, nmax=1 << 20):
+    loc = np.zeros((nmax, 5), np.float32)
+    des = np.zeros((nmax, 128), np.uint8)
+    fn = lib().orc_sift_read_ascii
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]
+    n = fn(os.fsencode(path), _p(loc), _p(des), nmax)
+    k = min(n, nmax)
+    return n, loc[:k].copy(), des[:k].copy()
+
+
+def sift_write_ascii(path, loc, des):
+    loc = np.ascontiguousarray(loc, np.float32)
+    des = np.ascontiguousarray(des, np.uint8)
+    fn = lib().orc_sift_write_ascii
+    fn.restype = C.c_long
+    fn.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]
+    return fn(os.fsencode(path), _p(loc), _p(des), len(des))
+
+
+def sift_sort(loc, des):
+    """SortSIFT on copies: (loc, des, order)."""
+    loc = np.array(loc, np.float32, order="C")
+    des = np.array(des, np.uint8, order="C")
+    order = np.zeros(max(len(des), 1), np.int32)
+    fn = lib().orc_sift_sort
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    fn(_p(loc), _p(des), len(des), _p(order))
+    return loc, des, order[:len(des)]
+
+
+def sift_convert_a2b(loc, des):
+    """The in-memory part of ConvertA2B on copies: (converted?, loc, des)."""
+    loc = np.array(loc, np.float32, order="C")
+    des = np.array(des, np.uint8, order="C")
+    fn = lib().orc_sift_convert_a2b
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    did = fn(_p(loc), _p(des), len(des))
+    return bool(did), loc, des
+
+
 def matchtxt_record(name0, name1, matches0):
     m = np.ascontiguousarray(matches0, np.int32)
     buf = C.create_string_buffer(64 + 32 * max(len(m), 1))

@@ -1,0 +1,173 @@
+"""ASCII .sift files, SortSIFT and the A2B conversion (FeaturePoints.cpp:54-125, 205-226, 498-513, 655-765)
+against the oracle's restatement of the same functions.  The reference holds no ASCII feature file of its
+own, so the inputs are synthetic files in Lowe's layout: parity unpinned beyond the restatement."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from visual_slam_amd import _binding as B
+from visual_slam_amd import host, synth
+
+
+def lowe_file(path, n, seed, unnormalised=False, ascending=False, ties=False):
+    """Lowe's keypoint text: 'n 128', per feature 'row col scale orientation' then 128 integers."""
+    rng = np.random.default_rng(seed)
+    des = synth.sift_like(n, rng)
+    if unnormalised:
+        des = (des // 2).astype(np.uint8)             # norm about 256: below the 400 that triggers the conversion
+    rows = rng.uniform(0, 1200, n)
+    cols = rng.uniform(0, 1600, n)
+    scale = rng.uniform(0.8, 30.0, n)
+    if ties:
+        scale = np.round(scale / 4) * 4               # many equal scales
+    scale = np.sort(scale) if ascending else scale
+    ori = rng.uniform(-np.pi, np.pi, n)
+    with open(path, "w") as f:
+        f.write("%d 128\n" % n)
+        for i in range(n):
+            f.write("%.2f %.2f %.2f %.3f\n" % (rows[i], cols[i], scale[i], ori[i]))
+            for k in range(0, 128, 20):
+                f.write(" " + " ".join(str(int(v)) for v in des[i, k:k + 20]) + "\n")
+    return des
+
+
+def test_ascii_reader_matches_oracle(tmp_path):
+    p = str(tmp_path / "a.key")
+    des = lowe_file(p, 300, 1)
+    loc, d = host.read_sift_ascii(p)
+    n, oloc, odes = orc.sift_read_ascii(p)
+    assert n == 300 and np.array_equal(d, odes) and np.array_equal(d, des)
+    assert np.array_equal(loc.view(np.uint32), oloc.view(np.uint32))
+    assert np.all(loc[:, 2] == 0) and np.all(loc[:, 3] > 0)
+    # first nmax only
+    loc2, d2 = host.read_sift_ascii(p, nmax=17)
+    assert np.array_equal(loc2, loc[:17]) and np.array_equal(d2, d[:17])
+
+
+def test_ascii_reader_keeps_low_bits_and_rejects_bad_files(tmp_path):
+    p = str(tmp_path / "b.key")
+    with open(p, "w") as f:
+        f.write("1 128\n1 2 3 0.5\n" + " ".join(["300"] * 128) + "\n")
+    _, d = host.read_sift_ascii(p)
+    n, _, od = orc.sift_read_ascii(p)
+    assert n == 1 and np.all(d == 300 - 256) and np.array_equal(d, od)
+    for text in ["", "0 128\n", "3 64\n", "2 128\n1 2 3 4\n" + " ".join(["1"] * 128) + "\n5 6 7\n", "1 128\n1 2 3 4 x\n"]:
+        with open(p, "w") as f:
+            f.write(text)
+        with pytest.raises(B.VsmError):
+            host.read_sift_ascii(p)
+    with pytest.raises(B.VsmError):
+        host.read_sift_ascii(str(tmp_path / "missing.key"))
+
+
+def test_ascii_writer_bytes_match_oracle_and_round_trip(tmp_path):
+    p = str(tmp_path / "a.key")
+    lowe_file(p, 120, 2)
+    loc, des = host.read_sift_ascii(p)
+    a, b = str(tmp_path / "lib.txt"), str(tmp_path / "orc.txt")
+    assert host.write_sift_ascii(a, loc, des) == 120
+    assert orc.sift_write_ascii(b, loc, des) == os.path.getsize(a)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    text = open(a).read().split("\n")
+    assert text[0] == "120 128" and len(text[2].split()) == 20 and text[2].endswith(" ")
+    # the written file reads back: saveSIFTA prints (loc[1], loc[0]) and the reader adds 0.5 to both again
+    loc2, des2 = host.read_sift_ascii(a)
+    assert np.array_equal(des2, des)
+    np.testing.assert_allclose(loc2[:, :2], loc[:, :2] + 0.5, rtol=1e-5)
+    # empty set: nothing is written, as the reference returns before opening the file
+    e = str(tmp_path / "empty.txt")
+    assert host.write_sift_ascii(e, np.zeros((0, 5), np.float32), np.zeros((0, 128), np.uint8)) == 0
+    assert not os.path.exists(e)
+
+
+@pytest.mark.parametrize("n,ties", [(1, False), (2, True), (257, False), (400, True)])
+def test_sort_matches_the_reference_bubble_sort(tmp_path, n, ties):
+    p = str(tmp_path / "a.key")
+    lowe_file(p, n, 3 + n, ties=ties)
+    loc, des = host.read_sift_ascii(p)
+    sl, sd, order = host.sort_sift(loc, des)
+    ol, od, oorder = orc.sift_sort(loc, des)
+    assert np.array_equal(order, oorder)
+    assert np.array_equal(sl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(sd, od)
+    assert np.all(np.diff(sl[:, 3]) <= 0)
+    assert np.array_equal(sl, loc[order]) and np.array_equal(sd, des[order])
+    if ties:
+        # equal scales: the later feature of the file comes first
+        same = np.nonzero(np.diff(sl[:, 3]) == 0)[0]
+        assert np.all(order[same] > order[same + 1])
+
+
+def test_reader_sorts_only_ascending_files(tmp_path):
+    p = str(tmp_path / "asc.key")
+    lowe_file(p, 200, 9, ascending=True)
+    loc, des = host.read_sift_ascii(p)
+    sl, sd = host.read_sift_ascii(p, nmax=50, sort=True)
+    el, ed, _ = orc.sift_sort(loc, des)
+    assert np.array_equal(sl, el[:50]) and np.array_equal(sd, ed[:50])
+    # a file whose first scale is not below its last one is taken as it is
+    q = str(tmp_path / "desc.key")
+    host.write_sift_ascii(q, el, ed)
+    l2, d2 = host.read_sift_ascii(q, nmax=50, sort=True)
+    assert np.array_equal(d2, ed[:50])
+
+
+def test_renormalise_matches_oracle(tmp_path):
+    p = str(tmp_path / "u.key")
+    lowe_file(p, 150, 4, unnormalised=True)
+    loc, des = host.read_sift_ascii(p)
+    des[7] = 0                                          # an all-zero row stays zero
+    did, l2, d2 = host.renormalise_sift(loc, des)
+    odid, ol, od = orc.sift_convert_a2b(loc, des)
+    assert did and odid
+    assert np.array_equal(d2, od) and np.array_equal(l2.view(np.uint32), ol.view(np.uint32))
+    assert np.array_equal(l2[:, 0], loc[:, 1]) and np.array_equal(l2[:, 1], loc[:, 0])
+    nrm = np.linalg.norm(d2.astype(np.float64), axis=1)
+    keep = np.arange(len(d2)) != 7
+    assert np.all(np.abs(nrm[keep] - 512) < 8) and np.all(d2[7] == 0)
+    # a set whose first descriptor already has norm 512 is left alone, locations included
+    did, l3, d3 = host.renormalise_sift(l2, d2)
+    odid, _, _ = orc.sift_convert_a2b(l2, d2)
+    assert not did and not odid and np.array_equal(l3, l2) and np.array_equal(d3, d2)
+
+
+def test_convert_a2b_file_names(tmp_path):
+    # x.sift.sift -> x.sift, the ASCII file is removed
+    p = str(tmp_path / "img.sift.sift")
+    lowe_file(p, 64, 5, unnormalised=True)
+    loc, des = host.read_sift_ascii(p)
+    _, el, ed = orc.sift_convert_a2b(loc, des)
+    name, n = host.convert_a2b(p)
+    assert n == 64 and name == str(tmp_path / "img.sift") and not os.path.exists(p)
+    bl, bd = host.read_sift(name)
+    assert np.array_equal(bl, el) and np.array_equal(bd, ed)
+    ref = str(tmp_path / "ref.sift")
+    orc.sift_write(ref, el, ed)
+    assert open(name, "rb").read() == open(ref, "rb").read()
+    # x.sift is overwritten in place
+    q = str(tmp_path / "two.sift")
+    lowe_file(q, 10, 6)
+    name, n = host.convert_a2b(q)
+    assert name == q and n == 10 and host.read_sift(q)[1].shape == (10, 128)
+    # any other name: nothing written
+    r = str(tmp_path / "three.key")
+    lowe_file(r, 10, 7)
+    before = open(r, "rb").read()
+    name, n = host.convert_a2b(r)
+    assert name is None and n == 10 and open(r, "rb").read() == before
+
+
+def test_tool_a2b(tmp_path):
+    import subprocess
+    import visual_slam_amd as vsm
+    tool = os.path.join(os.path.dirname(vsm.lib_path()), "vsm_sift_tool")
+    p = str(tmp_path / "7.sift.sift")
+    lowe_file(p, 32, 11, unnormalised=True)
+    loc, des = host.read_sift_ascii(p)
+    _, el, ed = orc.sift_convert_a2b(loc, des)
+    r = subprocess.run([tool, "a2b", p], capture_output=True, text=True)
+    assert r.returncode == 0 and "1 files, 32 features" in r.stderr
+    bl, bd = host.read_sift(str(tmp_path / "7.sift"))
+    assert np.array_equal(bl, el) and np.array_equal(bd, ed) and not os.path.exists(p)
+    assert subprocess.run([tool, "a2b", str(tmp_path / "none.sift")], capture_output=True).returncode == 1

@@ -87,6 +87,11 @@ SIGNATURES = {
     "vsm_last_submission_pairs": (C.c_int, [C.c_void_p]),
     "vsm_sift_read": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vsm_sift_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "vsm_sift_read_ascii": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "vsm_sift_write_ascii": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "vsm_sift_sort_by_scale": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vsm_sift_renormalise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "vsm_sift_ascii_to_binary": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
     "vsm_feature_txt_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int]),
     "vsm_feature_txt_read": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int]),
     "vsm_matchtxt_append_dense": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int]),

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -155,6 +156,206 @@ extern "C" int vsm_sift_write(const char* path, const float* loc, int nloc_dim,
     ok = ok && f.write_all(des, (size_t)npoint * VSM_DESC_DIM_U8);
     ok = ok && f.write_all(&eof, sizeof eof);
     return ok ? 1 : 0;
+}
+
+// ---- ASCII .sift (Lowe's keypoint text; FeaturePoints.cpp:54-125, 205-226) ---------------------------
+namespace {
+
+// Whitespace-separated tokens of a whole file held in memory.
+class Tokens {
+public:
+    explicit Tokens(std::string text) : text_(std::move(text)), p_(text_.c_str()) {}
+    bool next_float(float* v)
+    {
+        char* end = nullptr;
+        skip();
+        if (!*p_) return false;
+        *v = strtof(p_, &end);
+        if (end == p_) return false;
+        p_ = end;
+        return true;
+    }
+    bool next_uint(unsigned* v)
+    {
+        char* end = nullptr;
+        skip();
+        if (*p_ < '0' || *p_ > '9') return false;
+        *v = (unsigned)strtoul(p_, &end, 10);
+        p_ = end;
+        return true;
+    }
+    bool next_int(int* v)
+    {
+        char* end = nullptr;
+        skip();
+        if (!*p_) return false;
+        const long x = strtol(p_, &end, 10);
+        if (end == p_) return false;
+        *v = (int)x;
+        p_ = end;
+        return true;
+    }
+private:
+    void skip() { while (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r' || *p_ == '\f' || *p_ == '\v') ++p_; }
+    std::string text_;
+    const char* p_;
+};
+
+bool slurp(const char* path, std::string* out)
+{
+    Fd f(::open(path, O_RDONLY));
+    if (!f.ok()) return false;
+    struct stat st;
+    if (fstat(f.get(), &st) != 0 || st.st_size < 0) return false;
+    out->resize((size_t)st.st_size);
+    return f.read_upto(&(*out)[0], out->size()) == (ssize_t)out->size();
+}
+
+}  // namespace
+
+// FeatureData::ReadSIFTA + ReadFeatureDataA with four location values per feature (FeaturePoints.cpp:54-125):
+// "npoint ndim", then per feature "row col scale orientation" and ndim descriptor integers.  A stored
+// location is (col + 0.5, row + 0.5, 0, scale, -orientation); a descriptor value keeps its low 8 bits.
+extern "C" int vsm_sift_read_ascii(const char* path, float* locbuf, uint8_t* desbuf, int nmax, int* npoint)
+{
+    if (npoint) *npoint = 0;
+    std::string text;
+    if (!path || !slurp(path, &text)) return 0;
+    Tokens tok(std::move(text));
+    int n = 0, nd = 0;
+    if (!tok.next_int(&n) || !tok.next_int(&nd) || n <= 0 || nd != VSM_DESC_DIM_U8) return 0;
+    if (npoint) *npoint = n;
+    if (!locbuf && !desbuf) return n;
+    const int take = std::min(std::max(nmax, 0), n);
+    for (int i = 0; i < take; ++i) {
+        float row, col, scale, ori;
+        if (!tok.next_float(&row) || !tok.next_float(&col) || !tok.next_float(&scale) || !tok.next_float(&ori)) return 0;
+        if (locbuf) {
+            float* l = locbuf + (size_t)i * 5;
+            l[0] = col + 0.5f;
+            l[1] = row + 0.5f;
+            l[2] = 0.0f;
+            l[3] = scale;
+            l[4] = -ori;
+        }
+        for (int k = 0; k < VSM_DESC_DIM_U8; ++k) {
+            unsigned v;
+            if (!tok.next_uint(&v)) return 0;
+            if (desbuf) desbuf[(size_t)i * VSM_DESC_DIM_U8 + k] = (uint8_t)v;
+        }
+    }
+    return n;
+}
+
+// FeatureData::saveSIFTA (FeaturePoints.cpp:205-226): "n 128", then per feature "loc[1] loc[0] loc[3] loc[4]"
+// (as `ofstream << float` prints them) and the descriptor, every value followed by a blank, a line break after
+// every 20th value and one more after the last.  Nothing is written for an empty set, as there.
+extern "C" int vsm_sift_write_ascii(const char* path, const float* loc, const uint8_t* des, int npoint)
+{
+    if (!path || npoint < 0 || (npoint > 0 && (!loc || !des))) return VSM_EINVAL;
+    if (npoint == 0) return 0;
+    std::string out;
+    out.reserve((size_t)npoint * 600 + 32);
+    char num[64];
+    char* p = put_int(num, npoint);
+    *p++ = ' ';
+    p = put_int(p, VSM_DESC_DIM_U8);
+    *p++ = '\n';
+    out.append(num, p - num);
+    for (int i = 0; i < npoint; ++i) {
+        const float* l = loc + (size_t)i * 5;
+        const int len = snprintf(num, sizeof num, "%g %g %g %g\n", (double)l[1], (double)l[0], (double)l[3], (double)l[4]);
+        out.append(num, len);
+        for (int k = 0; k < VSM_DESC_DIM_U8; ++k) {
+            p = put_int(num, des[(size_t)i * VSM_DESC_DIM_U8 + k]);
+            *p++ = ' ';
+            if ((k + 1) % 20 == 0) *p++ = '\n';
+            out.append(num, p - num);
+        }
+        out.push_back('\n');
+    }
+    Fd f(::open(path, O_CREAT | O_WRONLY | O_TRUNC, 0644));
+    if (!f.ok() || !f.write_all(out.data(), out.size())) return VSM_EIO;
+    return npoint;
+}
+
+// FeatureData::SortSIFT (FeaturePoints.cpp:726-765): features by descending scale (location column 3).  The
+// reference bubble-sorts the REVERSED sequence with a strict comparison, so features of equal scale end up
+// in descending order of their old position; a stable sort of the reversed positions gives the same order.
+extern "C" int vsm_sift_sort_by_scale(float* loc, int nloc_dim, uint8_t* des, int npoint, int32_t* order)
+{
+    if (npoint < 0 || nloc_dim < 4 || (npoint > 0 && !loc)) return VSM_EINVAL;
+    std::vector<int32_t> ord((size_t)npoint);
+    for (int i = 0; i < npoint; ++i) ord[i] = npoint - 1 - i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+        return loc[(size_t)a * nloc_dim + 3] > loc[(size_t)b * nloc_dim + 3];
+    });
+    std::vector<float> l2((size_t)npoint * nloc_dim);
+    for (int i = 0; i < npoint; ++i)
+        memcpy(&l2[(size_t)i * nloc_dim], loc + (size_t)ord[i] * nloc_dim, sizeof(float) * nloc_dim);
+    if (npoint) memcpy(loc, l2.data(), l2.size() * sizeof(float));
+    if (des) {
+        std::vector<uint8_t> d2((size_t)npoint * VSM_DESC_DIM_U8);
+        for (int i = 0; i < npoint; ++i)
+            memcpy(&d2[(size_t)i * VSM_DESC_DIM_U8], des + (size_t)ord[i] * VSM_DESC_DIM_U8, VSM_DESC_DIM_U8);
+        if (npoint) memcpy(des, d2.data(), d2.size());
+    }
+    if (order && npoint) memcpy(order, ord.data(), sizeof(int32_t) * (size_t)npoint);
+    return npoint;
+}
+
+// The in-memory part of FeatureData::ConvertA2B (FeaturePoints.cpp:655-695): when the FIRST descriptor's L2 norm
+// is below 400 the set is taken to be in another convention: every descriptor is scaled to norm 512 and rounded
+// (floor(x + 0.5), in double), and the first two location values of every feature change places.
+extern "C" int vsm_sift_renormalise(float* loc, int nloc_dim, uint8_t* des, int npoint)
+{
+    if (npoint < 0 || (npoint > 0 && !des) || (loc && nloc_dim < 2)) return VSM_EINVAL;
+    if (npoint == 0) return 0;
+    double first = 0;
+    for (int k = 0; k < VSM_DESC_DIM_U8; ++k) first += (double)(des[k] * des[k]);
+    if (!(sqrt(first) < 400)) return 0;
+    for (int i = 0; i < npoint; ++i) {
+        uint8_t* d = des + (size_t)i * VSM_DESC_DIM_U8;
+        double sum = 0;
+        for (int k = 0; k < VSM_DESC_DIM_U8; ++k) sum += (double)(d[k] * d[k]);
+        if (sum == 0) continue;   // the reference divides by zero here; an all-zero row stays as it is
+        const double scale = 512.0 / sqrt(sum);
+        for (int k = 0; k < VSM_DESC_DIM_U8; ++k) {
+            const double v = floor(scale * d[k] + 0.5);
+            d[k] = (uint8_t)(unsigned)v;          // 512 at most: the low 8 bits, as the reference's cast keeps
+        }
+    }
+    if (loc)
+        for (int i = 0; i < npoint; ++i) std::swap(loc[(size_t)i * nloc_dim], loc[(size_t)i * nloc_dim + 1]);
+    return 1;
+}
+
+// ReadSIFTA followed by ConvertA2B (FeaturePoints.cpp:54-72, 655-710): the binary file takes the ASCII file's
+// place; "x.sift.sift" becomes "x.sift" and the ASCII file is removed, "x.sift" is overwritten, any other name
+// is left alone (nothing written, as there).  out_path receives the name written.
+extern "C" int vsm_sift_ascii_to_binary(const char* path, char* out_path, int cap)
+{
+    if (out_path && cap > 0) out_path[0] = 0;
+    if (!path) return VSM_EINVAL;
+    int n = 0;
+    if (!vsm_sift_read_ascii(path, nullptr, nullptr, 0, &n)) return VSM_EFORMAT;
+    std::vector<float> loc((size_t)n * 5);
+    std::vector<uint8_t> des((size_t)n * VSM_DESC_DIM_U8);
+    if (!vsm_sift_read_ascii(path, loc.data(), des.data(), n, nullptr)) return VSM_EFORMAT;
+    vsm_sift_renormalise(loc.data(), 5, des.data(), n);
+    std::string name(path);
+    const size_t len = name.size();
+    bool remove_ascii = false;
+    if (len > 10 && name.compare(len - 10, 10, ".sift.sift") == 0) {
+        name.resize(len - 5);
+        remove_ascii = true;
+    } else if (!(len > 5 && name.compare(len - 5, 5, ".sift") == 0)) {
+        return n;
+    }
+    if (!vsm_sift_write(name.c_str(), loc.data(), 5, des.data(), n)) return VSM_EIO;
+    if (remove_ascii) ::remove(path);
+    if (out_path && cap > 0) snprintf(out_path, (size_t)cap, "%s", name.c_str());
+    return n;
 }
 
 // =====================================================================================

@@ -133,6 +133,70 @@ def write_sift(path, loc, des):
         raise B.VsmError(-5, "cannot write %s" % path)
 
 
+# ---- ASCII .sift, sorting, the A2B conversion (FeaturePoints.cpp:54-125, 205-226, 655-765) ---------
+def read_sift_ascii(path, nmax=None, sort=False):
+    """FeatureData::ReadSIFTA: (loc float32 [n, 5] = (x + 0.5, y + 0.5, 0, scale, -orientation), des uint8 [n, 128]).
+    sort=True does what ReadSIFTA_DES does (FeaturePoints.cpp:498-513): SortSIFT when the first feature's
+    scale is below the last one's, before the first nmax are taken."""
+    npoint = C.c_int(0)
+    if not B.lib().vsm_sift_read_ascii(_b(path), None, None, 0, C.byref(npoint)):
+        raise B.VsmError(-6, "cannot read ASCII SIFT file %s" % path)
+    total = npoint.value
+    n = total if (nmax is None or sort) else min(nmax, total)
+    loc = np.empty((n, 5), np.float32)
+    des = np.empty((n, 128), np.uint8)
+    if not B.lib().vsm_sift_read_ascii(_b(path), B._ptr(loc), B._ptr(des), n, None):
+        raise B.VsmError(-6, "malformed ASCII SIFT file %s" % path)
+    if sort and n > 0 and loc[0, 3] < loc[n - 1, 3]:
+        loc, des, _ = sort_sift(loc, des)
+    if nmax is not None:
+        loc, des = loc[:nmax], des[:nmax]
+    return loc, des
+
+
+def write_sift_ascii(path, loc, des):
+    """FeatureData::saveSIFTA for loc [n, 5]."""
+    loc = np.ascontiguousarray(loc, dtype=np.float32)
+    des = np.ascontiguousarray(des, dtype=np.uint8)
+    if des.ndim != 2 or des.shape[1] != 128 or loc.shape != (des.shape[0], 5):
+        raise ValueError("expected loc [n, 5] and des [n, 128]")
+    rc = B.lib().vsm_sift_write_ascii(_b(path), B._ptr(loc), B._ptr(des), des.shape[0])
+    if rc < 0:
+        raise B.VsmError(rc, "vsm_sift_write_ascii(%s)" % path)
+    return rc
+
+
+def sort_sift(loc, des):
+    """FeatureData::SortSIFT on copies: (loc, des, order) by descending scale; order[i] = old row of new row i."""
+    loc = np.array(loc, dtype=np.float32, order="C")
+    des = np.array(des, dtype=np.uint8, order="C")
+    order = np.empty(max(len(des), 1), np.int32)
+    rc = B.lib().vsm_sift_sort_by_scale(B._ptr(loc), loc.shape[1], B._ptr(des), len(des), B._ptr(order))
+    if rc < 0:
+        raise B.VsmError(rc, "vsm_sift_sort_by_scale")
+    return loc, des, order[:len(des)]
+
+
+def renormalise_sift(loc, des):
+    """The in-memory part of FeatureData::ConvertA2B on copies: (converted?, loc, des)."""
+    loc = np.array(loc, dtype=np.float32, order="C")
+    des = np.array(des, dtype=np.uint8, order="C")
+    rc = B.lib().vsm_sift_renormalise(B._ptr(loc), loc.shape[1], B._ptr(des), len(des))
+    if rc < 0:
+        raise B.VsmError(rc, "vsm_sift_renormalise")
+    return bool(rc), loc, des
+
+
+def convert_a2b(path):
+    """ReadSIFTA + FeatureData::ConvertA2B: the binary .sift takes the ASCII file's place; returns (name written
+    or None, feature count)."""
+    out = C.create_string_buffer(4096)
+    n = B.lib().vsm_sift_ascii_to_binary(_b(path), out, len(out))
+    if n < 0:
+        raise B.VsmError(n, "vsm_sift_ascii_to_binary(%s)" % path)
+    return (os.fsdecode(out.value) if out.value else None), n
+
+
 # ---- .mat (MatchFile.cpp:751-958) -------------------------------------------------------------------
 def write_pmatch(image1, image2, fc1, fc2, idx1, idx2, reservation=0):
     i1 = np.ascontiguousarray(idx1, dtype=np.int32)
@@ -330,8 +394,7 @@ def estimate_fundamental(matcher, kpts0, kpts1, thresh, samples=256, seed=0):
     """Geometry of one pair from its matched keypoints, in the calling style of estimate_pose
     (models/utils.py:288-312: matched keypoint arrays in, model and inlier mask out; None when there
     are too few matches).  Returns (F [3, 3], mask [n] bool) with x1^T F x0 = 0; `thresh` is the Sampson
-    distance in pixels.  (The reference goes on to an essential matrix and a pose with the camera
-    intrinsics through OpenCV; that part is not rebuilt here.)"""
+    distance in pixels.  estimate_pose goes on from here to the relative pose with the camera intrinsics."""
     kpts0 = np.ascontiguousarray(kpts0, np.float32)
     kpts1 = np.ascontiguousarray(kpts1, np.float32)
     n = len(kpts0)
