@@ -92,6 +92,16 @@ enum { VSM_F32_FAST_EXACT = 0, VSM_F32_MFMA_F32 = 1 };
 int vsm_set_f32_mode(vsm_ctx* ctx, int mode);
 /* Which of the two ran in the last float search on this context (-1: none yet). */
 int vsm_last_f32_path(const vsm_ctx* ctx);
+/* Mutual check of float pair submissions (fast mode).  The reverse searches of a submission can run after the
+ * forward ones, over only the train rows that candidates which passed the score / distance / ratio tests name
+ * (VSM_F32_REVERSE_CANDIDATES), or together with them over every train row (VSM_F32_REVERSE_ALL).  Same lists
+ * either way.  VSM_F32_REVERSE_AUTO (default) takes the first for large submissions whose rule has such a
+ * test and the second otherwise (one launch less per stage matters for a single small pair). */
+enum { VSM_F32_REVERSE_AUTO = 0, VSM_F32_REVERSE_CANDIDATES = 1, VSM_F32_REVERSE_ALL = 2 };
+int vsm_set_f32_reverse(vsm_ctx* ctx, int mode);
+/* Which of the two the last float pair submission on this context took (VSM_F32_REVERSE_CANDIDATES or
+ * VSM_F32_REVERSE_ALL; -1: none yet, or no mutual check). */
+int vsm_last_f32_reverse(const vsm_ctx* ctx);
 /* How u8 (SIFT) sets are searched.  Both forms return the same bits (exact integer distances, lowest
  * index on ties).
  *   VSM_U8_AUTO (default): submissions with a ratio test run the tile-minimum query pass (the matrix

@@ -27,6 +27,15 @@ def f32_mode(matcher, request):
     matcher.set_f32_mode(vsm.F32_FAST_EXACT)
 
 
+@pytest.fixture(params=[vsm.F32_REVERSE_ALL, vsm.F32_REVERSE_CANDIDATES], ids=["both-directions", "candidates-only"])
+def reverse_mode(matcher, request):
+    """Pair tests run with the reverse searches of the mutual check over every train row, and over the
+    candidates' train rows only (what large submissions with a selective rule do by themselves)."""
+    matcher.set_f32_reverse(request.param)
+    yield request.param
+    matcher.set_f32_reverse(vsm.F32_REVERSE_AUTO)
+
+
 def _knn_check(matcher, a, b, metric):
     s0, s1 = matcher.upload_f32(a), matcher.upload_f32(b)
     try:
@@ -87,7 +96,7 @@ def test_layout_dim_major(matcher):
 
 
 @pytest.mark.parametrize("metric,ratio", [(vsm.METRIC_DOT, None), (vsm.METRIC_L2, 0.8), (vsm.METRIC_L2, None)])
-def test_match_dense_matches_oracle(matcher, metric, ratio):
+def test_match_dense_matches_oracle(matcher, metric, ratio, reverse_mode):
     a, b = synth.superpoint_pair(600, 700, 256, seed=8)
     s0, s1 = matcher.upload_f32(a), matcher.upload_f32(b)
     fr = (4, 5) if ratio else None
@@ -105,7 +114,7 @@ def test_match_dense_matches_oracle(matcher, metric, ratio):
     matcher.release(s1)
 
 
-def test_mutual_block_fixture(matcher):
+def test_mutual_block_fixture(matcher, reverse_mode):
     """Same outputs as the reference's mutual-argmax block run on the same descriptors."""
     z = np.load(os.path.join(G, "mutual_block.npz"))
     for tag in ("a", "b"):
@@ -269,7 +278,7 @@ def test_full_survivor_list_drops_stale_entries(matcher, f32_mode):
 @pytest.mark.parametrize("metric,ratio,mutual,dim", [(vsm.METRIC_DOT, None, True, 256), (vsm.METRIC_L2, 0.8, True, 256),
                                                      (vsm.METRIC_L2, 0.9, False, 256), (vsm.METRIC_DOT, None, True, 64),
                                                      (vsm.METRIC_L2, 0.8, True, 100)])
-def test_float_pairs_in_one_submission(matcher, metric, ratio, mutual, dim):
+def test_float_pairs_in_one_submission(matcher, metric, ratio, mutual, dim, reverse_mode):
     """Many float pairs per call (ragged sizes, an empty set, a one-row set) against the oracle pair by
     pair.  The submission is large enough for the eight-queries-per-wave re-rank kernel; single pairs
     elsewhere in this file run the wave-per-query one."""
@@ -396,7 +405,7 @@ def _check_float_pair_lists(imgs, pairs, off, i0, i1, metric, fr, mutual):
     return total
 
 
-def test_float_pair_list_cut_by_scratch_budget(matcher):
+def test_float_pair_list_cut_by_scratch_budget(matcher, reverse_mode):
     """A float pair list that does not fit one submission's scratch: match_pairs cuts it and runs the
     submissions one after the other; the lists equal the oracle's pair by pair."""
     rng = np.random.default_rng(71)
@@ -439,7 +448,7 @@ def test_more_float_pairs_than_one_submission_takes(matcher):
         matcher.release(sid)
 
 
-def test_config2_shape_4096_mutual(matcher):
+def test_config2_shape_4096_mutual(matcher, reverse_mode):
     """2 images x 4096 SuperPoint-256 descriptors, mutual nearest neighbour on the dot product: the
     launch the single-pair benchmark times (two searches + accept), dense and list forms."""
     a, b = synth.superpoint_pair(4096, 4096, 256, seed=77)
@@ -456,3 +465,43 @@ def test_config2_shape_4096_mutual(matcher):
     finally:
         matcher.release(s0)
         matcher.release(s1)
+
+
+def test_large_submission_searches_the_candidates_only(matcher, f32_mode):
+    """A submission of the size the pair-list benchmark times (20 pairs of 4096 x 4096, dot product, score
+    threshold, mutual): left to itself the library runs the reverse searches over the candidates' train rows
+    only; the lists equal those of the both-directions form, and the oracle's on two of the pairs."""
+    rng = np.random.default_rng(91)
+    pool = synth.unit_f32(4096, 256, rng)
+    imgs = []
+    for _ in range(7):
+        d = synth.unit_f32(4096, 256, rng)
+        k = 1024
+        noisy = pool[rng.choice(4096, k, replace=False)] + 0.05 * rng.standard_normal((k, 256)).astype(np.float32)
+        d[rng.choice(4096, k, replace=False)] = noisy / np.linalg.norm(noisy, axis=1, keepdims=True)
+        imgs.append(np.ascontiguousarray(d, np.float32))
+    ids = [matcher.upload_f32(d) for d in imgs]
+    pairs = [(a, b) for a in range(7) for b in range(a + 1, 7)][:20]
+    pr = np.asarray([[ids[a], ids[b]] for a, b in pairs], np.int32)
+    try:
+        off, i0, i1 = matcher.match_pairs(pr, ratio=None, mutual=True, metric=vsm.METRIC_DOT, min_score=0.5)
+        if f32_mode == vsm.F32_FAST_EXACT:
+            assert matcher.last_f32_reverse() == vsm.F32_REVERSE_CANDIDATES
+        matcher.set_f32_reverse(vsm.F32_REVERSE_ALL)
+        off2, j0, j1 = matcher.match_pairs(pr, ratio=None, mutual=True, metric=vsm.METRIC_DOT, min_score=0.5)
+        if f32_mode == vsm.F32_FAST_EXACT:
+            assert matcher.last_f32_reverse() == vsm.F32_REVERSE_ALL
+        np.testing.assert_array_equal(off, off2)
+        np.testing.assert_array_equal(i0, j0)
+        np.testing.assert_array_equal(i1, j1)
+        for k in (0, 19):
+            a, b = pairs[k]
+            o0, _, _, _ = orc.match_dense_f32(imgs[a], imgs[b], orc.METRIC_DOT, orc.params(None, True, min_score=0.5))
+            sel = np.nonzero(o0 >= 0)[0]
+            np.testing.assert_array_equal(i0[off[k]:off[k + 1]], sel)
+            np.testing.assert_array_equal(i1[off[k]:off[k + 1]], o0[sel])
+        assert off[-1] > 20 * 100
+    finally:
+        matcher.set_f32_reverse(vsm.F32_REVERSE_AUTO)
+        for sid in ids:
+            matcher.release(sid)

@@ -17,6 +17,9 @@ from ._binding import (  # noqa: F401
     LAYOUT_DIM_MAJOR,
     NO_SECOND,
     F32_FAST_EXACT,
+    F32_REVERSE_ALL,
+    F32_REVERSE_AUTO,
+    F32_REVERSE_CANDIDATES,
     F32_MFMA_F32,
     U8_AUTO,
     U8_PACKED,
@@ -48,7 +51,7 @@ from .host import (  # noqa: F401
 __all__ = [
     "VsmError", "Matcher", "lib", "lib_path",
     "METRIC_DOT", "METRIC_L2", "LAYOUT_ROWS", "LAYOUT_DIM_MAJOR", "NO_SECOND",
-    "F32_FAST_EXACT", "F32_MFMA_F32", "U8_AUTO", "U8_PACKED",
+    "F32_FAST_EXACT", "F32_MFMA_F32", "F32_REVERSE_AUTO", "F32_REVERSE_CANDIDATES", "F32_REVERSE_ALL", "U8_AUTO", "U8_PACKED",
     "generate_imagePairs", "generate_exhaustive_pairs", "get_list_matching_pairs",
     "save_matching_sfm", "save_feature_locations", "read_feature_locations",
     "read_sift", "write_sift", "write_pmatch", "get_pmatch", "get_pmatch_r", "get_match_count",

@@ -10,6 +10,7 @@ LAYOUT_ROWS, LAYOUT_DIM_MAJOR = 0, 1
 NO_SECOND = 2**31 - 1
 F32_FAST_EXACT = 0
 F32_MFMA_F32 = 1
+F32_REVERSE_AUTO, F32_REVERSE_CANDIDATES, F32_REVERSE_ALL = 0, 1, 2
 U8_AUTO = 0
 U8_PACKED = 1
 
@@ -56,6 +57,8 @@ SIGNATURES = {
     "vsm_upload_f32_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vsm_set_scratch_budget": (C.c_int, [C.c_void_p, C.c_longlong]),
     "vsm_set_f32_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "vsm_set_f32_reverse": (C.c_int, [C.c_void_p, C.c_int]),
+    "vsm_last_f32_reverse": (C.c_int, [C.c_void_p]),
     "vsm_last_f32_path": (C.c_int, [C.c_void_p]),
     "vsm_set_u8_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "vsm_last_u8_path": (C.c_int, [C.c_void_p]),
@@ -452,6 +455,14 @@ class Matcher:
     def set_f32_mode(self, mode):
         """0 = bf16 coarse pass + exact re-rank (default), 1 = f32 matrix cores only; same results."""
         self._check(self._l.vsm_set_f32_mode(self._h, int(mode)))
+
+    def set_f32_reverse(self, mode):
+        """Mutual check of float pair submissions: 0 = choose by size and rule, 1 = reverse searches over the
+        candidates' train rows only, 2 = both directions in one launch; same results."""
+        self._check(self._l.vsm_set_f32_reverse(self._h, int(mode)))
+
+    def last_f32_reverse(self):
+        return self._l.vsm_last_f32_reverse(self._h)
 
     def set_u8_mode(self, mode):
         """0 = tile-minimum query pass for ratio-test submissions (default), 1 = packed form only; same results."""

@@ -14,6 +14,16 @@
 // dot - |b|^2 / 2 (half the exact key; the accumulators start from -|b|^2 / 2), which adds the f32
 // rounding of partial sums of that size: 2 * 256 * 2^-24 * max|b|^2 / 2 on top of 2 eps.
 // Inputs are assumed finite and far from the ends of the f32 exponent range.
+//
+// Two reductions of the work for callers that need less than the two best rows of every query:
+//  * top1: only the best row matters.  The threshold is then T1 - 2 eps (T1 = the largest coarse score): the
+//    exact best row scores at least what the coarse-best row scores exactly, which is >= T1 - eps, so its own
+//    coarse score is >= T1 - 2 eps; rows that tie with it exactly satisfy the same bound.
+//  * key_floor (dot ranking): a row whose exact score is not above the floor cannot be accepted by the caller's
+//    score test, and a row above it has coarse score > floor - eps; the threshold never drops below that.
+//    Queries whose best score is not above the floor come out with no row at all (-1).
+// And a query list (qlist / qcount) restricts a search to some rows of A, chosen on the device by an earlier
+// kernel: the mutual check of a pair only asks about the train rows that some query row has chosen.
 #include "f32_kernels.h"
 
 #include <math.h>
@@ -155,7 +165,7 @@ __device__ __forceinline__ int find_problem(int nprobs, int L, GetFirst first)
     return lo;
 }
 
-template <int DIMP>
+template <int DIMP, bool TOP1>
 __global__ __launch_bounds__(kCoarseWaves * 64, 2)
 void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
                         CoarsePart* __restrict__ part_all, uint2* __restrict__ lists_all, int* __restrict__ overflow)
@@ -185,6 +195,9 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
     uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
     const int Lp = L - P.blk0;
     const int split = Lp / nstrips, strip = Lp % nstrips;
+    const int32_t* __restrict__ qlist = P.qlist;
+    const int nq = qlist ? *P.qcount : pr.nA;
+    if (strip * kCoarseStripRows >= nq) return;   // the whole strip is past the end of the query list
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -195,20 +208,34 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
 
     // persistent operands: this wave's RB x 32 queries
     v8bf qf[RB][S];
-    float margin[RB], thr[RB], b1[RB], b2[RB];
+    float margin[RB], floorc[RB], thr[RB], b1[RB], b2[RB];
     int cnt[RB];
     const int qidx0 = ((strip * kCoarseWaves + wave) * RB) * 32 + lane5;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-        const int qtile = (strip * kCoarseWaves + wave) * RB + rb;
-        const v8bf* src = reinterpret_cast<const v8bf*>(bfA + (size_t)qtile * S * 512) + lane;
+        const int qi = qidx0 + rb * 32;               // query slot
+        const bool real = qi < nq;
+        int qrow = qi;
+        if (qlist) {
+            // the operands of this lane's own row, out of whichever tile holds it
+            qrow = real ? qlist[qi] : 0;
+            const v8bf* src = reinterpret_cast<const v8bf*>(bfA + (size_t)(qrow >> 5) * S * 512) + half * 32 + (qrow & 31);
 #pragma unroll
-        for (int s = 0; s < S; ++s) qf[rb][s] = src[s * 64];
-        const int qi = qidx0 + rb * 32;
-        margin[rb] = coarse_margin(l2, pr.nrmA[qi], maxnb);
+            for (int s = 0; s < S; ++s) qf[rb][s] = src[s * 64];
+        } else {
+            const int qtile = (strip * kCoarseWaves + wave) * RB + rb;
+            const v8bf* src = reinterpret_cast<const v8bf*>(bfA + (size_t)qtile * S * 512) + lane;
+#pragma unroll
+            for (int s = 0; s < S; ++s) qf[rb][s] = src[s * 64];
+        }
+        margin[rb] = coarse_margin(l2, pr.nrmA[qrow], maxnb);
+        floorc[rb] = l2 ? -INFINITY : P.key_floor - 0.5f * margin[rb];
         // padded queries never append
-        thr[rb] = qi < pr.nA ? -INFINITY : INFINITY;
-        if (qi >= pr.nA) margin[rb] = -INFINITY;
+        thr[rb] = real ? -INFINITY : INFINITY;
+        if (!real) {
+            margin[rb] = -INFINITY;
+            floorc[rb] = INFINITY;
+        }
         b1[rb] = -INFINITY;
         b2[rb] = -INFINITY;
         cnt[rb] = 0;
@@ -261,15 +288,22 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 float tmax = -INFINITY;
+                if (TOP1) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float x0 = acc[rb][2 * e], x1 = acc[rb][2 * e + 1];
-                    const float u = __builtin_amdgcn_fmed3f(b1[rb], x0, x1);
-                    b1[rb] = fmaxf(fmaxf(b1[rb], x0), x1);
-                    tmax = fmaxf(fmaxf(tmax, x0), x1);
-                    b2[rb] = fmaxf(b2[rb], u);
+                    for (int e = 0; e < 8; ++e) tmax = fmaxf(fmaxf(tmax, acc[rb][2 * e]), acc[rb][2 * e + 1]);
+                    b1[rb] = fmaxf(b1[rb], tmax);
+                    thr[rb] = fmaxf(b1[rb] - margin[rb], floorc[rb]);   // padded queries: NaN or +inf against +inf
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x0 = acc[rb][2 * e], x1 = acc[rb][2 * e + 1];
+                        const float u = __builtin_amdgcn_fmed3f(b1[rb], x0, x1);
+                        b1[rb] = fmaxf(fmaxf(b1[rb], x0), x1);
+                        tmax = fmaxf(fmaxf(tmax, x0), x1);
+                        b2[rb] = fmaxf(b2[rb], u);
+                    }
+                    thr[rb] = fmaxf(b2[rb] - margin[rb], floorc[rb]);   // padded queries: NaN or +inf against +inf
                 }
-                thr[rb] = b2[rb] - margin[rb];   // +inf for padded queries, NaN (never reached) before they see two rows
                 if (tmax >= thr[rb]) {
                     // some of this lane's 16 rows reach the threshold as it stands after this tile (no row
                     // below it can be among the final survivors): one list entry for the tile, with a bit
@@ -380,18 +414,22 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
     const int nsplits = P.nsplits;
     const CoarsePart* __restrict__ part = part_all + P.part_off;
     const uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
-    const int i = (int)blockIdx.x * kRerankWaves + wave;
-    const bool live = i < pr.nA;
+    const int i = (int)blockIdx.x * kRerankWaves + wave;   // query slot
+    const int32_t* __restrict__ qlist = P.qlist;
+    const int nq = qlist ? *P.qcount : pr.nA;
+    const bool live = i < nq;
+    const int qrow = live ? (qlist ? qlist[i] : i) : 0;
     if (live && lane * 4 < DIMP)
         *reinterpret_cast<float4*>(&s_a[wave][lane * 4]) =
-            *reinterpret_cast<const float4*>(P.rowsA + (size_t)i * DIMP + lane * 4);
+            *reinterpret_cast<const float4*>(P.rowsA + (size_t)qrow * DIMP + lane * 4);
     __syncthreads();   // the only workgroup barrier: everything below is per wave
     if (!live) return;
 
     volatile int* rows = s_rows[wave];
     const bool l2 = pr.metric == 1;
-    const float na = pr.nrmA[i];
+    const float na = pr.nrmA[qrow];
     const float margin = coarse_margin(l2, na, *P.maxnormB_sq);
+    const float floorc = l2 ? -INFINITY : P.key_floor - 0.5f * margin;
     const int nsub = nsplits * 2;
     auto sub_index = [&](int sid) { return ((size_t)(sid >> 1) * pr.nA_pad + i) * 2 + (sid & 1); };
 
@@ -410,7 +448,7 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
         T2 = fmaxf(fmaxf(T2, o2), fminf(T1, o1));
         T1 = fmaxf(T1, o1);
     }
-    const float thr = T2 - margin;
+    const float thr = fmaxf((P.top1 ? T1 : T2) - margin, floorc);
 
     Best2 best;
     best.s1 = -INFINITY; best.s2 = -INFINITY; best.r1 = -1; best.r2 = -1;
@@ -542,8 +580,12 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
     const int sub = lane & 7, grp = lane >> 3, gbase = lane & ~7;
     const CoarseProblem& P = probs[blockIdx.y];
     const F32Problem pr = P.pr;
-    const int i = ((int)blockIdx.x * kGroupWaves + wave) * 8 + grp;
-    const bool live = i < pr.nA;
+    const int i = ((int)blockIdx.x * kGroupWaves + wave) * 8 + grp;   // query slot
+    const int32_t* __restrict__ qlist = P.qlist;
+    const int nslots = qlist ? *P.qcount : pr.nA;
+    if ((int)blockIdx.x * kGroupQueries >= nslots) return;   // the whole block is past the end of the query list
+    const bool live = i < nslots;
+    const int qrow = live ? (qlist ? qlist[i] : i) : 0;
     volatile int* queue = s_queue[wave][grp];
     volatile float* score = s_score[wave][grp];
     const int nsub = P.nsplits * 2;
@@ -552,14 +594,15 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
     auto sub_index = [&](int sid) { return ((size_t)(sid >> 1) * pr.nA_pad + i) * 2 + (sid & 1); };
 
     if (live) {
-        const float4* pa = reinterpret_cast<const float4*>(P.rowsA + (size_t)i * DIMP) + sub * Q;
+        const float4* pa = reinterpret_cast<const float4*>(P.rowsA + (size_t)qrow * DIMP) + sub * Q;
         float4* dst = reinterpret_cast<float4*>(&s_a[wave][grp][0]) + sub * Q;
 #pragma unroll
         for (int u = 0; u < Q; ++u) dst[u] = pa[u];
     }
     const bool l2 = pr.metric == 1;
-    const float na = live ? pr.nrmA[i] : 0.0f;
+    const float na = live ? pr.nrmA[qrow] : 0.0f;
     const float margin = coarse_margin(l2, na, *P.maxnormB_sq);
+    const float floorc = l2 ? -INFINITY : P.key_floor - 0.5f * margin;
 
     // final coarse runner-up over all splits and both lane halves
     float T1 = -INFINITY, T2 = -INFINITY;
@@ -578,7 +621,7 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
         T2 = fmaxf(fmaxf(T2, o2), fminf(T1, o1));
         T1 = fmaxf(T1, o1);
     }
-    const float thr = T2 - margin;
+    const float thr = fmaxf((P.top1 ? T1 : T2) - margin, floorc);
     __syncthreads();   // query rows staged
 
     Best2 best;   // the same in every lane of the group
@@ -696,13 +739,14 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
 // ---------------------------------------------------------------------------------
 // planning and launch
 // ---------------------------------------------------------------------------------
-CoarseTotals plan_coarse(CoarseProblem* probs, int n, int target_wgs)
+CoarseTotals plan_coarse(CoarseProblem* probs, int n, int target_wgs, int64_t out_rows0)
 {
     long long unsplit = 0;
     for (int i = 0; i < n; ++i) unsplit += probs[i].pr.nA_pad / kCoarseStripRows;
     // database splits per problem: only as many as it takes to fill the chip
     const int want = unsplit >= target_wgs || unsplit == 0 ? 1 : (int)((target_wgs + unsplit - 1) / unsplit);
     CoarseTotals t;
+    t.out_rows = out_rows0;
     for (int i = 0; i < n; ++i) {
         CoarseProblem& p = probs[i];
         const int ntiles = p.pr.nB_pad / 32;
@@ -713,8 +757,6 @@ CoarseTotals plan_coarse(CoarseProblem* probs, int n, int target_wgs)
         p.tiles_per_split = tps;
         p.nsplits = std::max(1, (ntiles + tps - 1) / tps);
         p.blk0 = t.coarse_blocks;
-        p.rr_blk0 = 0;
-        p.reserved = 0;
         p.part_off = t.sublists;
         p.out_off = t.out_rows;
         t.coarse_blocks += p.nstrips * p.nsplits;
@@ -733,28 +775,34 @@ size_t coarse_scratch_bytes(const CoarseTotals& t)
     return part_bytes(t.sublists) + (size_t)t.sublists * kCoarseCap * sizeof(uint2) + 256;
 }
 
-template <int DIMP>
+template <int DIMP, bool TOP1>
 static void launch_coarse_t(const CoarseProblem* d_probs, int nprobs, int blocks, CoarsePart* part, uint2* lists,
                             int* overflow, hipStream_t s)
 {
     const int lds = 2 * kCoarseStepBytes;
-    static DeviceFlags attr_set;   // the attribute is per device
-    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(bf16_coarse_kernel<DIMP>), lds);
-    hipLaunchKernelGGL(bf16_coarse_kernel<DIMP>, dim3(blocks), dim3(kCoarseWaves * 64), lds, s,
+    static DeviceFlags attr_set;   // the attribute is per device (and per instantiation: one flag set each)
+    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(bf16_coarse_kernel<DIMP, TOP1>), lds);
+    hipLaunchKernelGGL((bf16_coarse_kernel<DIMP, TOP1>), dim3(blocks), dim3(kCoarseWaves * 64), lds, s,
                        d_probs, nprobs, part, lists, overflow);
 }
 
 void launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
                        int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow,
-                       hipStream_t s)
+                       hipStream_t s, bool top1)
 {
     if (nprobs <= 0 || t.coarse_blocks <= 0) return;
     CoarsePart* part = static_cast<CoarsePart*>(scratch);
     uint2* lists = reinterpret_cast<uint2*>(static_cast<char*>(scratch) + part_bytes(t.sublists));
     const int dimp = f32_dimp(dim);
-    if (dimp == 64) launch_coarse_t<64>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
-    else if (dimp == 128) launch_coarse_t<128>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
-    else launch_coarse_t<256>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
+    if (top1) {
+        if (dimp == 64) launch_coarse_t<64, true>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
+        else if (dimp == 128) launch_coarse_t<128, true>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
+        else launch_coarse_t<256, true>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
+    } else {
+        if (dimp == 64) launch_coarse_t<64, false>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
+        else if (dimp == 128) launch_coarse_t<128, false>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
+        else launch_coarse_t<256, false>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
+    }
     if (t.rerank_blocks <= 0) return;
     // many queries with few sublists each: eight queries per wave; few queries with many sublists
     // (a sliced database): one wave per query

@@ -91,10 +91,14 @@ struct CoarseProblem {
     const float* rowsB;
     int32_t nstrips, nsplits, tiles_per_split;
     int32_t blk0;               // first workgroup of the coarse grid that belongs to this problem
-    int32_t rr_blk0;            // unused (the re-rank grid is two-dimensional: query block x problem)
-    int32_t reserved;
+    int32_t top1;               // 1: only the best row of a query matters (j2 / k2 are then meaningless)
+    float key_floor;            // dot ranking: rows whose exact score is not above it cannot matter (-inf: none)
     int64_t part_off;           // first survivor sublist (sublists: [split][query][lane half])
     int64_t out_off;            // first output row in j1 / j2 / k1 / k2
+    // Optional query list: query slot q (< *qcount <= pr.nA) is row qlist[q] of A; parts, lists and outputs
+    // are indexed by slot, and pr.nA / pr.nA_pad are then the capacity of the list, not A's row count.
+    const int32_t* qlist;
+    const int32_t* qcount;
 };
 
 struct CoarseTotals {
@@ -106,14 +110,15 @@ struct CoarseTotals {
 
 // Fills the geometry and offsets of n problems (pr, bf*, initB, maxnormB_sq already set) so that the
 // whole submission has about `target_wgs` coarse workgroups when the databases allow it.
-CoarseTotals plan_coarse(CoarseProblem* probs, int n, int target_wgs);
+// out_rows0: first output row (a second group of problems of the same submission continues after the first).
+CoarseTotals plan_coarse(CoarseProblem* probs, int n, int target_wgs, int64_t out_rows0 = 0);
 size_t coarse_scratch_bytes(const CoarseTotals& t);
-// All problems must share f32_dimp(dim).  Outputs as launch_f32_knn's query side at out_off, bit for
+// All problems must share f32_dimp(dim) and top1.  Outputs as launch_f32_knn's query side at out_off, bit for
 // bit, PROVIDED *overflow (device int, cleared by the caller) reads 0 afterwards; a set flag means a
 // survivor list was too short and the results are void.
 void launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
                        int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow,
-                       hipStream_t s);
+                       hipStream_t s, bool top1 = false);
 
 // L2 searches only (problems of the other metric are skipped): orders each query's two best rows by the
 // difference-form squared distance and stores those distances in k1 / k2.  Problems come from device memory

@@ -364,13 +364,13 @@ __global__ void f32_l2_finish_kernel(const CoarseProblem* __restrict__ probs, Co
 {
     const CoarseProblem& p = use_single ? single : probs[blockIdx.y];
     if (p.pr.metric != 1) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.pr.nA) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // query slot
+    if (i >= (p.qlist ? *p.qcount : p.pr.nA)) return;
     const size_t o = (size_t)p.out_off + i;
     int a1 = j1[o], a2 = j2[o];
     if (a1 < 0) return;
     const int dimp = f32_dimp(p.pr.dim);
-    const float4* qa = reinterpret_cast<const float4*>(p.rowsA + (size_t)i * dimp);
+    const float4* qa = reinterpret_cast<const float4*>(p.rowsA + (size_t)(p.qlist ? p.qlist[i] : i) * dimp);
     const float4* r1 = reinterpret_cast<const float4*>(p.rowsB + (size_t)a1 * dimp);
     const float4* r2 = reinterpret_cast<const float4*>(p.rowsB + (size_t)(a2 < 0 ? a1 : a2) * dimp);
     float d1 = 0.0f, d2 = 0.0f;

@@ -73,6 +73,55 @@ void launch_f32_accept(const SiftPair* pairs, const F32PairRef* refs, int npairs
     hipLaunchKernelGGL(f32_accept_kernel, dim3(npairs), dim3(1024), 0, s, pairs, refs, rule, j1, k1, k2, out);
 }
 
+__global__ __launch_bounds__(1024)
+void f32_confirm_kernel(const SiftPair* __restrict__ pairs, const F32PairRef* __restrict__ refs,
+                        const int32_t* __restrict__ j1, SiftOutputs out)
+{
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const SiftPair pw = pairs[blockIdx.x];
+    const F32PairRef rf = refs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int ncand = out.counts[blockIdx.x];
+    if (tid == 0) base_s = 0;
+    if (out.dense0)
+        for (int i = tid; i < pw.nA; i += 1024) out.dense0[pw.out0_off + i] = -1;
+    if (out.dense1)
+        for (int jj = tid; jj < pw.nB; jj += 1024) out.dense1[pw.out1_off + jj] = -1;
+    __syncthreads();
+    // in place: a kept candidate moves to a slot at or before its own, and a round reads its 1024 candidates
+    // before any of them is written
+    for (int k0 = 0; k0 < ncand; k0 += 1024) {
+        const int k = k0 + tid;
+        int i = -1, j = -1, d = 0;
+        bool ok = false;
+        if (k < ncand) {
+            i = out.slot_i0[pw.out0_off + k];
+            j = out.slot_i1[pw.out0_off + k];
+            if (out.slot_d) d = out.slot_d[pw.out0_off + k];
+            ok = rf.bwd_off >= 0 && j1[rf.bwd_off + k] == i;
+        }
+        const int slot = block_compact_slot(ok, wsum, &base_s);
+        if (ok) {
+            const size_t o = pw.out0_off + slot;
+            out.slot_i0[o] = i;
+            out.slot_i1[o] = j;
+            if (out.slot_d) out.slot_d[o] = d;
+            if (out.dense0) out.dense0[pw.out0_off + i] = j;
+            if (out.dense1) out.dense1[pw.out1_off + j] = i;   // mutual: one query row per train row
+        }
+    }
+    __syncthreads();
+    if (tid == 0) out.counts[blockIdx.x] = base_s;
+}
+
+void launch_f32_confirm(const SiftPair* pairs, const F32PairRef* refs, int npairs, const int32_t* j1,
+                        SiftOutputs out, hipStream_t s)
+{
+    if (npairs <= 0) return;
+    hipLaunchKernelGGL(f32_confirm_kernel, dim3(npairs), dim3(1024), 0, s, pairs, refs, j1, out);
+}
+
 __global__ void gather_words_kernel(WordSegments seg, uint32_t* __restrict__ dst)
 {
     int base = 0;

@@ -108,6 +108,7 @@ struct vsm_ctx {
     DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_probs, d_geom, d_short;
     // float sets: 0 = bf16 coarse pass + exact re-rank (exact kernel when a survivor list overflows), 1 = exact kernel only
     int f32_mode = 0, last_f32_path = -1;
+    int f32_reverse = VSM_F32_REVERSE_AUTO, last_f32_reverse = -1;
     // u8 sets: 0 = the tile-minimum query pass for ratio-test submissions (packed form otherwise), 1 = packed form only
     int u8_mode = 0, last_u8_path = -1;
     int* flag_dev = nullptr;   // survivor-overflow flag of the last coarse submission (inside d_probs)
@@ -714,6 +715,8 @@ CoarseProblem make_problem(const DescSet* A, const DescSet* B, int metric)
     p.maxnormB_sq = sb.maxnorm_sq;
     p.rowsA = sa.rows_f32;
     p.rowsB = sb.rows_f32;
+    p.top1 = 0;
+    p.key_floor = -INFINITY;
     return p;
 }
 
@@ -884,10 +887,12 @@ int match_pair_f32(vsm_ctx* c, const DescSet* A, const DescSet* B, const vsm_par
 
 // ---- submissions of float pairs: coarse + re-rank for every search, accept tests on the device ----
 struct F32Plan {
-    std::vector<CoarseProblem> probs;
+    std::vector<CoarseProblem> probs;   // image 0 -> image 1 searches, then (mutual check) the reverse ones
+    int nfwd = 0;                       // how many of them are forward searches
     std::vector<SiftPair> pairs;     // only the counts and output offsets are used
     std::vector<F32PairRef> refs;    // problem indices while planning, row offsets once planned
     size_t out0 = 0, out1 = 0;
+    double work = 0;                 // sum of rows x rows over the forward searches
     int dim = 0;
 };
 
@@ -915,13 +920,17 @@ int plan_f32(vsm_ctx* c, const int32_t* pairs, int npairs, int metric, bool mutu
         if (A->n > 0 && B->n > 0) {
             rf.fwd_off = (int64_t)pl.probs.size();
             pl.probs.push_back(make_problem(A, B, metric));
-            if (mutual) {
-                rf.bwd_off = (int64_t)pl.probs.size();
-                pl.probs.push_back(make_problem(B, A, metric));
-            }
+            pl.work += (double)A->n * (double)B->n;
         }
         pl.refs[p] = rf;
     }
+    pl.nfwd = (int)pl.probs.size();
+    if (mutual)
+        for (int p = 0; p < npairs; ++p) {
+            if (pl.refs[p].fwd_off < 0) continue;
+            pl.refs[p].bwd_off = (int64_t)pl.probs.size();
+            pl.probs.push_back(make_problem(get_set(c, pairs[2 * p + 1]), get_set(c, pairs[2 * p]), metric));
+        }
     if (pl.dim == 0) pl.dim = 256;
     if (pl.probs.size() > 65535)   // one grid row of the re-rank kernel per search
         return fail(c, VSM_EINVAL, "%zu searches in one submission (limit 65535); submit fewer pairs per call", pl.probs.size());
@@ -941,34 +950,26 @@ F32Rule make_f32_rule(const vsm_params* p, int metric)
 }
 
 // Queues the whole float pipeline for one planned submission; the caller reads the overflow flag.
+//
+// Dot ranking: only the best row of a query is ever asked for here, and no row at or below the score
+// threshold can be accepted, so the searches run in their top-1 form with that floor.
+// Mutual check of a large submission whose tests reject most rows: the forward searches and the accept tests
+// run first, and the reverse searches then ask only about the train rows the surviving candidates name (the
+// candidate list of a pair, as it lies in the output slots, is the reverse search's query list).  Small
+// submissions, and rules that pass nearly every row, run both directions in one launch instead.
 int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o)
 {
     const int npairs = (int)pl.pairs.size();
+    const int nprobs = (int)pl.probs.size(), nfwd = pl.nfwd, nrev = nprobs - nfwd;
+    const bool dot = rule.metric == VSM_METRIC_DOT;
+    const bool selective = dot ? rule.min_score > -INFINITY : (rule.ratio_num > 0 || rule.max_dist >= 0.0f);
+    const bool two_phase = nrev > 0 && (c->f32_reverse == VSM_F32_REVERSE_CANDIDATES ||
+                                        (c->f32_reverse == VSM_F32_REVERSE_AUTO && selective && pl.work >= (double)(1 << 28)));
     c->R().ev_valid = false;
     c->timing_slot = c->rs;
-    if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
-    // the pair records and their references to the searches travel in the same copy as the problems
-    const size_t pair_bytes = (sizeof(SiftPair) * (size_t)npairs + 255) & ~(size_t)255;
-    const size_t ref_bytes = sizeof(F32PairRef) * (size_t)npairs;
-    char* extra_dev = nullptr;
-    int rc = queue_coarse(c, pl.probs, pl.dim, 0, pair_bytes + ref_bytes, [&](char* h) {
-        // plan_coarse has run: problem offsets are final
-        for (F32PairRef& rf : pl.refs) {
-            if (rf.fwd_off >= 0) rf.fwd_off = pl.probs[rf.fwd_off].out_off;
-            if (rf.bwd_off >= 0) rf.bwd_off = pl.probs[rf.bwd_off].out_off;
-        }
-        if (npairs) {
-            memcpy(h, pl.pairs.data(), sizeof(SiftPair) * npairs);
-            memcpy(h + pair_bytes, pl.refs.data(), ref_bytes);
-        }
-    }, &extra_dev);
-    if (rc) return rc;
-    if (c->timing) {
-        HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
-        c->R().ev_valid = true;
-    }
-    const SiftPair* d_pairs = reinterpret_cast<const SiftPair*>(extra_dev);
-    const F32PairRef* d_refs = reinterpret_cast<const F32PairRef*>(extra_dev + pair_bytes);
+    c->last_f32_reverse = nrev == 0 ? -1 : two_phase ? VSM_F32_REVERSE_CANDIDATES : VSM_F32_REVERSE_ALL;
+
+    // output slots first: the candidate lists in them are the query lists of the reverse searches
     const size_t n0 = std::max<size_t>(pl.out0, 1), n1 = std::max<size_t>(pl.out1, 1);
     HIPCHK(c, c->d_slot0.ensure(n0 * 4));
     HIPCHK(c, c->d_slot1.ensure(n0 * 4));
@@ -983,10 +984,79 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
         HIPCHK(c, c->d_dense0.ensure(n0 * 4));
         HIPCHK(c, c->d_dense1.ensure(n1 * 4));
     }
+
+    for (CoarseProblem& p : pl.probs) {
+        p.top1 = dot ? 1 : 0;
+        p.key_floor = dot ? rule.min_score : -INFINITY;
+    }
+    if (two_phase)
+        for (int p = 0; p < npairs; ++p) {
+            const F32PairRef& rf = pl.refs[p];
+            if (rf.bwd_off < 0) continue;
+            CoarseProblem& q = pl.probs[rf.bwd_off];
+            // capacity of the list = the forward search's query rows
+            q.pr.nA = pl.pairs[p].nA;
+            q.pr.nA_pad = pl.pairs[p].nA_pad;
+            q.qlist = c->d_slot1.as<int32_t>() + pl.pairs[p].out0_off;
+            q.qcount = c->d_counts.as<int32_t>() + p;
+        }
+    // geometry and offsets: one group when both directions go in one launch, else two
+    CoarseTotals t1, t2;
+    if (two_phase) {
+        t1 = plan_coarse(pl.probs.data(), nfwd, 1024);
+        t2 = plan_coarse(pl.probs.data() + nfwd, nrev, 1024, t1.out_rows);
+    } else {
+        t1 = plan_coarse(pl.probs.data(), nprobs, 1024);
+        t2 = t1;
+    }
+    const size_t rows = std::max<size_t>((size_t)t2.out_rows, 1);
+    HIPCHK(c, c->d_knnj.ensure(rows * 4));
+    HIPCHK(c, c->d_rrj.ensure(rows * 4));
+    HIPCHK(c, c->d_knn1.ensure(rows * 4));
+    HIPCHK(c, c->d_knn2.ensure(rows * 4));
+    HIPCHK(c, c->d_coarse.ensure(std::max(coarse_scratch_bytes(t1), coarse_scratch_bytes(t2))));
+    HIPCHK(c, c->h_small.ensure(64));
+    for (F32PairRef& rf : pl.refs) {
+        if (rf.fwd_off >= 0) rf.fwd_off = pl.probs[rf.fwd_off].out_off;
+        if (rf.bwd_off >= 0) rf.bwd_off = pl.probs[rf.bwd_off].out_off;
+    }
+    // one host-to-device copy: [flag, 256 bytes][problems][pair records][references to the searches]
+    const size_t pbytes = (sizeof(CoarseProblem) * (size_t)nprobs + 255) & ~(size_t)255;
+    const size_t pair_bytes = (sizeof(SiftPair) * (size_t)npairs + 255) & ~(size_t)255;
+    const size_t ref_bytes = sizeof(F32PairRef) * (size_t)npairs;
+    const size_t bytes = 256 + pbytes + pair_bytes + ref_bytes;
+    HIPCHK(c, c->h_probs.ensure(bytes));
+    HIPCHK(c, c->d_probs.ensure(bytes));
+    char* h = c->h_probs.as<char>();
+    memset(h, 0, 256);
+    if (nprobs) memcpy(h + 256, pl.probs.data(), sizeof(CoarseProblem) * (size_t)nprobs);
+    if (npairs) {
+        memcpy(h + 256 + pbytes, pl.pairs.data(), sizeof(SiftPair) * (size_t)npairs);
+        memcpy(h + 256 + pbytes + pair_bytes, pl.refs.data(), ref_bytes);
+    }
+    if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_probs.p, h, bytes, hipMemcpyHostToDevice, c->stream));
+    c->flag_dev = c->d_probs.as<int>();
+    const CoarseProblem* d_probs = reinterpret_cast<const CoarseProblem*>(c->d_probs.as<char>() + 256);
+    const SiftPair* d_pairs = reinterpret_cast<const SiftPair*>(c->d_probs.as<char>() + 256 + pbytes);
+    const F32PairRef* d_refs = reinterpret_cast<const F32PairRef*>(c->d_probs.as<char>() + 256 + pbytes + pair_bytes);
     if (npairs == 0) {
         HIPCHK(c, hipMemsetAsync(c->R().d_offsets.p, 0, sizeof(int64_t), c->stream));
         return VSM_OK;
     }
+    int32_t* j1 = c->d_knnj.as<int32_t>();
+    int32_t* j2 = c->d_rrj.as<int32_t>();
+    float* k1 = c->d_knn1.as<float>();
+    float* k2 = c->d_knn2.as<float>();
+    auto search = [&](const CoarseProblem* dp, const CoarseProblem* hp, int n, const CoarseTotals& t) {
+        if (n <= 0) return;
+        launch_bf16_batch(dp, n, pl.dim, t, j1, j2, k1, k2, c->d_coarse.p, c->flag_dev, c->stream, dot);
+        if (!dot) {
+            int max_rows = 0;
+            for (int i = 0; i < n; ++i) max_rows = std::max(max_rows, hp[i].pr.nA);
+            launch_f32_l2_finish(dp, n, max_rows, nullptr, j1, j2, k1, k2, c->stream);
+        }
+    };
     SiftOutputs out{};
     out.slot_i0 = c->d_slot0.as<int32_t>();
     out.slot_i1 = c->d_slot1.as<int32_t>();
@@ -994,8 +1064,24 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     out.counts = c->d_counts.as<int32_t>();
     out.dense0 = o.want_dense ? c->d_dense0.as<int32_t>() : nullptr;
     out.dense1 = o.want_dense ? c->d_dense1.as<int32_t>() : nullptr;
-    launch_f32_accept(d_pairs, d_refs, npairs, rule, c->d_knnj.as<int32_t>(),
-                      c->d_knn1.as<float>(), c->d_knn2.as<float>(), out, c->stream);
+    if (two_phase) {
+        search(d_probs, pl.probs.data(), nfwd, t1);
+        F32Rule first = rule;
+        first.mutual = 0;
+        SiftOutputs cand = out;
+        cand.dense0 = nullptr;
+        cand.dense1 = nullptr;
+        launch_f32_accept(d_pairs, d_refs, npairs, first, j1, k1, k2, cand, c->stream);
+        search(d_probs + nfwd, pl.probs.data() + nfwd, nrev, t2);
+        launch_f32_confirm(d_pairs, d_refs, npairs, j1, out, c->stream);
+    } else {
+        search(d_probs, pl.probs.data(), nprobs, t1);
+        launch_f32_accept(d_pairs, d_refs, npairs, rule, j1, k1, k2, out, c->stream);
+    }
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
+        c->R().ev_valid = true;
+    }
     if (o.want_pack)
         launch_pack(d_pairs, npairs, out.counts, c->R().d_offsets.as<int64_t>(), out.slot_i0, out.slot_i1,
                     c->R().d_tight0.as<int32_t>(), c->R().d_tight1.as<int32_t>(), c->stream);
@@ -1782,7 +1868,16 @@ extern "C" int vsm_set_f32_mode(vsm_ctx* c, int mode)
     return VSM_OK;
 }
 
+extern "C" int vsm_set_f32_reverse(vsm_ctx* c, int mode)
+{
+    if (!c) return VSM_EINVAL;
+    if (mode < VSM_F32_REVERSE_AUTO || mode > VSM_F32_REVERSE_ALL) return fail(c, VSM_EINVAL, "unknown reverse mode %d", mode);
+    c->f32_reverse = mode;
+    return VSM_OK;
+}
+
 extern "C" int vsm_last_f32_path(const vsm_ctx* c) { return c ? c->last_f32_path : VSM_EINVAL; }
+extern "C" int vsm_last_f32_reverse(const vsm_ctx* c) { return c ? c->last_f32_reverse : VSM_EINVAL; }
 
 extern "C" int vsm_knn2_device(vsm_ctx* c, int set_q, int set_db, int metric, void* packed_dev)
 {

@@ -159,6 +159,12 @@ struct F32Rule {
 void launch_f32_accept(const SiftPair* pairs, const F32PairRef* refs, int npairs, F32Rule rule,
                        const int32_t* j1, const float* k1, const float* k2, SiftOutputs out, hipStream_t s);
 
+// Second half of a mutual check whose reverse searches ran on the candidates only: candidate k of a pair
+// (slot_i0 / slot_i1 / slot_d at out0_off + k, k < counts[pair]) stays when the reverse search of slot k
+// (j1[bwd_off + k]) names its query row.  Compacts the lists in place, rewrites counts, fills the dense forms.
+void launch_f32_confirm(const SiftPair* pairs, const F32PairRef* refs, int npairs, const int32_t* j1,
+                        SiftOutputs out, hipStream_t s);
+
 // device merge of per-slice 2-NN lists; packed = [nslices][4][nq] words (key1, key2, row1, row2)
 void launch_merge_top2(const int32_t* packed, const int64_t* base, int nslices, int nq, int metric,
                        float* ok1, float* ok2, int64_t* oi1, int64_t* oi2, hipStream_t s);
