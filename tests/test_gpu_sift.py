@@ -279,6 +279,35 @@ def test_undecidable_candidates_are_rescanned(matcher):
             matcher.release(s1)
 
 
+def test_ties_between_chunks_with_merged_chunk_records(matcher):
+    """A single pair of many query rows is cut into narrow train chunks whose partial results are merged by a
+    pass of their own before the candidates are chosen: exact copies of train rows placed in different chunks
+    (the nearest distance tied between chunks), and runner-ups in another chunk than the winner."""
+    rng = np.random.default_rng(23)
+    a = synth.sift_like(5000, rng)
+    b = synth.sift_like(6000, rng)
+    for k in range(300):
+        b[13 * k] = a[11 * k]                    # d1 = 0
+        if k % 3 == 0:
+            b[5999 - 7 * k] = a[11 * k]          # the same row again, thousands of rows later
+        else:
+            t = a[11 * k].copy()
+            t[k % 128] = t[k % 128] + 1 if t[k % 128] < 255 else 254
+            b[5999 - 7 * k] = t                  # a runner-up one unit away, far from the winner
+    s0, s1 = matcher.upload_u8(a), matcher.upload_u8(b)
+    try:
+        for ratio in ((4, 5), (1, 1), (1, 100)):
+            for mutual in (True, False):
+                g0, g1, gd = matcher.match_pair(s0, s1, ratio=ratio[0] / ratio[1], mutual=mutual, return_dist=True)
+                o0, o1, od = orc.match_u8(a, b, orc.params(ratio, mutual))
+                np.testing.assert_array_equal(g0, o0)
+                np.testing.assert_array_equal(g1, o1)
+                np.testing.assert_array_equal(gd, od)
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)
+
+
 def test_parity_of_the_runner_up_decides(matcher):
     """d1 * den^2 < num^2 * d2 with d2 straddling the boundary: rows built so that the true runner-up
     distance is 2 k or 2 k + 1 around the value where the test flips."""

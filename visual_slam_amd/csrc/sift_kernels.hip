@@ -485,10 +485,50 @@ void launch_sift_query_tile(const SiftPair* pairs, const SiftItem* items, int ni
 // Chunk merge and OPTIMISTIC tests: the nearest row's exact distance is 2 y1 + (0 or 1) + nrm(a), the
 // runner-up's is at most 2 k2 + 1 + nrm(a), so a row that fails with d1 at its lowest and d2 at its highest
 // fails for certain; everything else becomes a candidate for the resolve pass.
+//
+// The chunk merge of one row: chunks in ascending order, the first of equal minima keeps its tile.
+__device__ __forceinline__ void merge_chunk_row(int e1, int et, int e2, int& y1, int& tl, int& y2)
+{
+    if (e1 < y1) {       // a tie between chunks leaves y2 == y1: the resolve pass rescans
+        y2 = min(y1, e2);
+        y1 = e1;
+        tl = et;
+    } else {
+        y2 = min(y2, e1);
+    }
+}
+
+// Pairs cut into several chunks (few pairs of many rows): the select pass has one workgroup per pair, whose
+// walk over chunks x rows is then a long chain of dependent loads.  This pass merges the chunks with the whole
+// grid, four rows per thread, and leaves the result in chunk 0's records; the select pass then reads those only.
+__global__ __launch_bounds__(256)
+void sift_merge_chunks_kernel(const SiftPair* __restrict__ pairs, int32_t* __restrict__ rr_y1,
+                              int32_t* __restrict__ rr_tile, int32_t* __restrict__ rr_k2)
+{
+    const SiftPair pw = pairs[blockIdx.y];
+    const int ib = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (ib >= pw.nA || pw.nchunks < 2) return;
+    int4 y1 = make_int4(kYPad, kYPad, kYPad, kYPad), y2 = y1, tl = make_int4(0, 0, 0, 0);
+    for (int c = 0; c < pw.nchunks; ++c) {
+        const size_t o = pw.row_off + (size_t)c * pw.nA_pad + ib;
+        const int4 v1 = *reinterpret_cast<const int4*>(rr_y1 + o);
+        const int4 vt = *reinterpret_cast<const int4*>(rr_tile + o);
+        const int4 v2 = *reinterpret_cast<const int4*>(rr_k2 + o);
+        merge_chunk_row(v1.x, vt.x, v2.x, y1.x, tl.x, y2.x);
+        merge_chunk_row(v1.y, vt.y, v2.y, y1.y, tl.y, y2.y);
+        merge_chunk_row(v1.z, vt.z, v2.z, y1.z, tl.z, y2.z);
+        merge_chunk_row(v1.w, vt.w, v2.w, y1.w, tl.w, y2.w);
+    }
+    const size_t o = pw.row_off + ib;
+    *reinterpret_cast<int4*>(rr_y1 + o) = y1;
+    *reinterpret_cast<int4*>(rr_tile + o) = tl;
+    *reinterpret_cast<int4*>(rr_k2 + o) = y2;
+}
+
 __global__ __launch_bounds__(1024)
 void sift_select_tile_kernel(const SiftPair* __restrict__ pairs,
                              const int32_t* __restrict__ rr_y1, const int32_t* __restrict__ rr_tile,
-                             const int32_t* __restrict__ rr_k2, MatchRule rule, SiftCandidates cand)
+                             const int32_t* __restrict__ rr_k2, int merged, MatchRule rule, SiftCandidates cand)
 {
     __shared__ int wsum[16];
     __shared__ int base_s;
@@ -505,7 +545,8 @@ void sift_select_tile_kernel(const SiftPair* __restrict__ pairs,
 #pragma unroll
         for (int r = 0; r < R; ++r) { tl[r] = 0; y1[r] = kYPad; y2[r] = kYPad; }
         if (ib < pw.nA) {
-            for (int c = 0; c < pw.nchunks; ++c) {
+            const int nchunks = merged ? min(pw.nchunks, 1) : pw.nchunks;
+            for (int c = 0; c < nchunks; ++c) {
                 const size_t o = pw.row_off + (size_t)c * pw.nA_pad + ib;
                 int e1[R], et[R], e2[R];
 #pragma unroll
@@ -518,15 +559,7 @@ void sift_select_tile_kernel(const SiftPair* __restrict__ pairs,
                     e2[4 * q] = v2.x; e2[4 * q + 1] = v2.y; e2[4 * q + 2] = v2.z; e2[4 * q + 3] = v2.w;
                 }
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (e1[r] < y1[r]) {       // a tie between chunks leaves y2 == y1: the resolve pass rescans
-                        y2[r] = min(y1[r], e2[r]);
-                        y1[r] = e1[r];
-                        tl[r] = et[r];
-                    } else {
-                        y2[r] = min(y2[r], e1[r]);
-                    }
-                }
+                for (int r = 0; r < R; ++r) merge_chunk_row(e1[r], et[r], e2[r], y1[r], tl[r], y2[r]);
             }
         }
         unsigned okbits = 0;
@@ -561,11 +594,17 @@ void sift_select_tile_kernel(const SiftPair* __restrict__ pairs,
     if (tid == 0) cand.count[blockIdx.x] = base_s;
 }
 
-void launch_sift_select_tile(const SiftPair* pairs, int npairs, const int32_t* rr_y1, const int32_t* rr_tile,
-                             const int32_t* rr_k2, MatchRule rule, SiftCandidates cand, hipStream_t s)
+void launch_sift_select_tile(const SiftPair* pairs, int npairs, int max_rows, int max_chunks, int32_t* rr_y1,
+                             int32_t* rr_tile, int32_t* rr_k2, MatchRule rule, SiftCandidates cand, hipStream_t s)
 {
+    // a merged record of a one-chunk pair is the record itself; a first tie between chunks that the merge
+    // turned into y2 == y1 stays one when the select pass reads the merged record
+    const bool merge = max_chunks > 1 && max_rows >= 4096;
+    if (merge)
+        hipLaunchKernelGGL(sift_merge_chunks_kernel, dim3((max_rows + 1023) / 1024, npairs), dim3(256), 0, s,
+                           pairs, rr_y1, rr_tile, rr_k2);
     hipLaunchKernelGGL(sift_select_tile_kernel, dim3(npairs), dim3(1024), 0, s,
-                       pairs, rr_y1, rr_tile, rr_k2, rule, cand);
+                       pairs, rr_y1, rr_tile, rr_k2, merge ? 1 : 0, rule, cand);
 }
 
 // ---- 2c. resolve / rescan ------------------------------------------------------------------

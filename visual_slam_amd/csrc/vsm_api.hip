@@ -349,9 +349,12 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
             out.knn_d2 = c->d_knn2.as<int32_t>();
         }
         if (tile_path) {
-            int max_rows = 0;
-            for (const SiftPair& sp : pl.pairs) max_rows = std::max(max_rows, sp.nA);
-            launch_sift_select_tile(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(),
+            int max_rows = 0, max_chunks = 0;
+            for (const SiftPair& sp : pl.pairs) {
+                max_rows = std::max(max_rows, sp.nA);
+                max_chunks = std::max(max_chunks, sp.nchunks);
+            }
+            launch_sift_select_tile(c->d_pairs.as<SiftPair>(), npairs, max_rows, max_chunks, c->d_rr1.as<int32_t>(),
                                     c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, c->stream);
             launch_sift_resolve(c->d_pairs.as<SiftPair>(), npairs, max_rows, rule, cand, c->stream);
         } else {

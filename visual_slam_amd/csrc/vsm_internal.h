@@ -183,8 +183,8 @@ void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
 // one tile (row, exact distance, exact tests), rescan of the few rows one tile cannot settle.
 void launch_sift_query_tile(const SiftPair* pairs, const SiftItem* items, int nitems,
                             int32_t* rr_y1, int32_t* rr_tile, int32_t* rr_k2, hipStream_t s);
-void launch_sift_select_tile(const SiftPair* pairs, int npairs, const int32_t* rr_y1, const int32_t* rr_tile,
-                             const int32_t* rr_k2, MatchRule rule, SiftCandidates cand, hipStream_t s);
+void launch_sift_select_tile(const SiftPair* pairs, int npairs, int max_rows, int max_chunks, int32_t* rr_y1,
+                             int32_t* rr_tile, int32_t* rr_k2, MatchRule rule, SiftCandidates cand, hipStream_t s);
 void launch_sift_resolve(const SiftPair* pairs, int npairs, int max_rows, MatchRule rule, SiftCandidates cand,
                          hipStream_t s);
 // chunk merge + distance/ratio tests -> candidate lists (+ raw 2-NN outputs)
