@@ -14,6 +14,7 @@
 #include "vsm_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace vsm {
 
@@ -472,9 +473,121 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
     }
 }
 
+// ---- 1c. the same pass on v_mfma_i32_16x16x64_i8 (experimental) ------------------------------
+// A wave's 128 query rows are 8 column blocks of 16 (lane l: column l & 15); a 32-row tile is 2 row blocks
+// of 16, K = 128 two steps of 64 (lane quarter q = l >> 4 holds k = 64 c + 16 q .. + 15 of both operands,
+// and accumulator registers 0..3 hold rows 4 q .. 4 q + 3 of the row block).  Operands are read out of the
+// same fragment-major arrays: bytes k = 32 s + 16 h .. + 15 of row r of a tile lie at s * 1024 + (h * 32 + r) * 16.
+__global__ __launch_bounds__(kQueryWaves * 64, 2)
+void sift_query_tile16_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ items,
+                              int32_t* __restrict__ rr_y1, int32_t* __restrict__ rr_tile,
+                              int32_t* __restrict__ rr_k2)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SiftItem it = items[xcd_contiguous_item(blockIdx.x, gridDim.x)];
+    const SiftPair pw = pairs[it.pair];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, quad = lane >> 4;
+
+    const int c0 = it.chunk * pw.chunk_cols;
+    const int ncols = min(pw.chunk_cols, pw.nB_pad - c0);
+    const int nsteps = ncols / kStepRows;
+
+    // byte offset, inside a tile, of this lane's 16 operand bytes of k-step c (0, 1) and row block rb (0, 1)
+    const int lane_off = ((quad >> 1) * 1024) + ((quad & 1) * 32 + l16) * 16;
+    constexpr int kCB = 8;
+    const int qtile = (it.strip * (kStripRows / 32)) + wave * kQueryRB;
+    v4i pf[kCB][2];
+#pragma unroll
+    for (int cb = 0; cb < kCB; ++cb) {
+        const int8_t* src = pw.fragA + (size_t)(qtile + (cb >> 1)) * kTileBytes + lane_off + (cb & 1) * 256;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) pf[cb][c] = ~*reinterpret_cast<const v4i*>(src + c * 2048);
+    }
+
+    const int8_t* Bsrc = pw.fragB + (size_t)(c0 >> 5) * kTileBytes + wave * (kLdsTile / kQueryWaves) + lane * 16;
+    const int32_t* Csrc = pw.nrmB + pw.nB_pad + c0 + (wave & 3) * 64 + lane;
+
+    int k1[kCB], k2[kCB], kt[kCB];
+#pragma unroll
+    for (int cb = 0; cb < kCB; ++cb) { k1[cb] = kYPad; k2[cb] = kYPad; kt[cb] = 0; }
+
+    stage_step<kQueryWaves>(smem, 0, Bsrc, Csrc, wave);
+    __syncthreads();
+
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nsteps)
+            stage_step<kQueryWaves>(smem, cur ^ 1, Bsrc + (size_t)(st + 1) * kLdsTile, Csrc + (st + 1) * kStepRows, wave);
+        const char* Bt = smem + cur * kLdsTile + lane_off;
+        const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm) + quad * 4;
+        const int tile0 = (c0 >> 5) + st * kTilesPerStep;
+#pragma unroll
+        for (int t = 0; t < kTilesPerStep; ++t) {
+            const char* tile = Bt + t * 4096;
+            v4i a[2][2], cv[2];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                a[rb][0] = *reinterpret_cast<const v4i*>(tile + rb * 256);
+                a[rb][1] = *reinterpret_cast<const v4i*>(tile + rb * 256 + 2048);
+                cv[rb] = *reinterpret_cast<const v4i*>(nl + t * 32 + rb * 16);
+            }
+#pragma unroll
+            for (int cb = 0; cb < kCB; ++cb) {
+                v4i z0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0][0], pf[cb][0], cv[0], 0, 0, 0);
+                v4i z1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1][0], pf[cb][0], cv[1], 0, 0, 0);
+                z0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0][1], pf[cb][1], z0, 0, 0, 0);
+                z1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1][1], pf[cb][1], z1, 0, 0, 0);
+                int m = min(min(z0[0], z0[1]), z0[2]);
+                m = min(min(m, z0[3]), z1[0]);
+                m = min(min(m, z1[1]), z1[2]);
+                m = min(m, z1[3]);
+                k2[cb] = med3i(k1[cb], k2[cb], m);
+                kt[cb] = m < k1[cb] ? tile0 + t : kt[cb];
+                k1[cb] = min(k1[cb], m);
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int cb = 0; cb < kCB; ++cb) {
+        // the four lane quarters saw disjoint 8-row groups of every tile for the same query row
+        int y1 = k1[cb], y2 = k2[cb], tl = kt[cb];
+#pragma unroll
+        for (int d = 16; d <= 32; d <<= 1) {
+            const int o1 = __shfl_xor(y1, d);
+            const int o2 = __shfl_xor(y2, d);
+            const int ot = __shfl_xor(tl, d);
+            const bool other = o1 < y1 || (o1 == y1 && ot < tl);
+            y2 = min(max(y1, o1), min(y2, o2));
+            tl = other ? ot : tl;
+            y1 = min(y1, o1);
+        }
+        if (quad == 0) {
+            const int grow = qtile * 32 + cb * 16 + l16;
+            const size_t o = pw.row_off + (size_t)it.chunk * pw.nA_pad + grow;
+            rr_y1[o] = y1;
+            rr_tile[o] = tl;
+            rr_k2[o] = y2;
+        }
+    }
+}
+
 void launch_sift_query_tile(const SiftPair* pairs, const SiftItem* items, int nitems,
                             int32_t* rr_y1, int32_t* rr_tile, int32_t* rr_k2, hipStream_t s)
 {
+    static const bool use16 = getenv("VSM_QT16") != nullptr;
+    if (use16) {
+        static DeviceFlags attr16;
+        ensure_dynamic_lds(attr16, reinterpret_cast<const void*>(sift_query_tile16_kernel), kLdsStream);
+        hipLaunchKernelGGL(sift_query_tile16_kernel, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
+                           pairs, items, rr_y1, rr_tile, rr_k2);
+        return;
+    }
     static DeviceFlags attr_set;   // the attribute is per device
     ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(sift_query_tile_kernel), kLdsStream);
     hipLaunchKernelGGL(sift_query_tile_kernel, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
