@@ -14,7 +14,6 @@
 #include "vsm_internal.h"
 
 #include <algorithm>
-#include <cstdlib>
 
 namespace vsm {
 
@@ -318,168 +317,25 @@ void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
 
 // ---- 1b. query pass, tile-minimum form ---------------------------------------------------
 // The form above spends 2.25 vector instructions per distance (scale + pack, running two smallest), which
-// makes the vector issue port, not the matrix pipe, its limit.  This form spends 0.75:
+// makes the vector issue port, not the matrix pipe, its limit.  This form spends 1.0:
 //   * the accumulators start from the train rows' constants cq and the query operand is ~p, so the MFMA
 //     result is the half-distance y = floor(nrm(q) / 2) - p.q itself (no per-element arithmetic);
-//   * per lane and 32-row tile only the minimum m of the 16 values is taken (eight v_min3), then
-//     k2 = med3(k1, k2, m), tile = m < k1 ? this tile : tile, k1 = min(k1, m).
+//   * per lane and 32-row tile only the minimum m of the lane's 8 values of a query row is taken (four
+//     v_min / v_min3), then k2 = med3(k1, k2, m), tile = m < k1 ? this tile : tile, k1 = min(k1, m).
 // A lane therefore knows the smallest y of its query row (k1), the first tile that holds it, and the
-// second smallest of the per-(tile, lane half) minima (k2): an upper bound of the runner-up that misses only
-// rows of the winner's own 16-row group.  What this leaves open -- which row of the tile, the parity bit
+// second smallest of the per-(tile, lane quarter) minima (k2): an upper bound of the runner-up that misses only
+// rows of the winner's own 8-row group.  What this leaves open -- which row of the tile, the parity bit
 // that y drops, a runner-up inside the winner's group -- is settled for the candidates only, from that one
 // tile (sift_resolve_kernel), and in the rare undecidable case by a scan of the whole train set
 // (sift_rescan_kernel).  Results are bit-identical to the packed form's.
-__global__ __launch_bounds__(kQueryWaves * 64, 2)
-void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ items,
-                            int32_t* __restrict__ rr_y1, int32_t* __restrict__ rr_tile,
-                            int32_t* __restrict__ rr_k2)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const SiftItem it = items[xcd_contiguous_item(blockIdx.x, gridDim.x)];
-    const SiftPair pw = pairs[it.pair];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane5 = lane & 31;
-    const int half = lane >> 5;
-
-    const int c0 = it.chunk * pw.chunk_cols;
-    const int ncols = min(pw.chunk_cols, pw.nB_pad - c0);
-    const int nsteps = ncols / kStepRows;
-
-    // persistent operand: this wave's query rows, complemented (~p = -p - 1; cq holds the + sum(q))
-    const int qtile = (it.strip * (kStripRows / 32)) + wave * kQueryRB;
-    v4i pf[kQueryRB][4];
-#pragma unroll
-    for (int rb = 0; rb < kQueryRB; ++rb) {
-        const int8_t* src = pw.fragA + (size_t)(qtile + rb) * kTileBytes + lane * 16;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) pf[rb][s] = ~*reinterpret_cast<const v4i*>(src + s * 1024);
-    }
-
-    const int8_t* Bsrc = pw.fragB + (size_t)(c0 >> 5) * kTileBytes + wave * (kLdsTile / kQueryWaves) + lane * 16;
-    const int32_t* Csrc = pw.nrmB + pw.nB_pad + c0 + (wave & 3) * 64 + lane;
-
-    int k1[kQueryRB], k2[kQueryRB], kt[kQueryRB];
-#pragma unroll
-    for (int rb = 0; rb < kQueryRB; ++rb) { k1[rb] = kYPad; k2[rb] = kYPad; kt[rb] = 0; }
-
-    // Software pipeline, written out because the compiler's own schedule reads a tile's operands from LDS
-    // right before its first MFMA and runs a tile's whole epilogue before the next tile's reads (3 % slower):
-    //   * the operands and constants of tile t + 1 are read while tile t multiplies;
-    //   * the epilogues of query blocks 2 and 3 trail by half a tile: they run between the MFMAs of blocks
-    //     0, 1 and of blocks 2, 3 of the NEXT tile, so every epilogue has MFMAs of other blocks in flight and
-    //     no accumulator set is live twice (four sets, as before).
-    // acc[2], acc[3] start as "nothing": their first (pending) epilogue changes no state.
-    static_assert(kQueryRB == 4, "the pipeline below is written for four query blocks per wave");
-    v16i acc[kQueryRB];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { acc[2][e] = kYPad; acc[3][e] = kYPad; }
-    int pend_tile = 0;
-
-    auto load_tile = [&](const char* tile, const int* ctile, v4i (&b)[4], v16i& cv) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b[s] = *reinterpret_cast<const v4i*>(tile + s * 1024);
-        int c[16];
-        tile_consts(ctile, half, c);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) cv[e] = c[e];
-    };
-    auto mma = [&](int rb, const v4i (&b)[4], const v16i& cv) {
-        v16i z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[0], pf[rb][0], cv, 0, 0, 0);
-        z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[1], pf[rb][1], z, 0, 0, 0);
-        z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[2], pf[rb][2], z, 0, 0, 0);
-        z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[3], pf[rb][3], z, 0, 0, 0);
-        acc[rb] = z;
-    };
-    auto epilogue = [&](int rb, int tileno) {
-        // plain min() on the accumulator registers (the compiler folds pairs into v_min3_i32): what reads
-        // an MFMA result must be visible to the compiler, which places the wait states the hardware needs
-        // between the matrix pipe's write and a vector read; inline assembly is not
-        int m = min(min(acc[rb][0], acc[rb][1]), acc[rb][2]);
-#pragma unroll
-        for (int e = 0; e < 6; ++e) m = min(min(m, acc[rb][3 + 2 * e]), acc[rb][4 + 2 * e]);
-        m = min(m, acc[rb][15]);
-        k2[rb] = med3i(k1[rb], k2[rb], m);          // k1 <= k2: the runner-up of {k1, k2, m}
-        kt[rb] = m < k1[rb] ? tileno : kt[rb];      // strict: the first tile that holds the minimum
-        k1[rb] = min(k1[rb], m);
-    };
-
-    stage_step<kQueryWaves>(smem, 0, Bsrc, Csrc, wave);
-    __syncthreads();
-
-    for (int st = 0; st < nsteps; ++st) {
-        const int cur = st & 1;
-        if (st + 1 < nsteps)
-            stage_step<kQueryWaves>(smem, cur ^ 1, Bsrc + (size_t)(st + 1) * kLdsTile, Csrc + (st + 1) * kStepRows, wave);
-        const char* Bt = smem + cur * kLdsTile + lane * 16;
-        const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm);
-        const int tile0 = (c0 >> 5) + st * kTilesPerStep;
-        v4i b[2][4];
-        v16i cv[2];
-        load_tile(Bt, nl, b[0], cv[0]);
-        epilogue(2, pend_tile);
-        epilogue(3, pend_tile);
-#pragma unroll
-        for (int t = 0; t < kTilesPerStep; ++t) {
-            if (t + 1 < kTilesPerStep) load_tile(Bt + (t + 1) * 4096, nl + (t + 1) * 32, b[(t + 1) & 1], cv[(t + 1) & 1]);
-            mma(0, b[t & 1], cv[t & 1]);
-            mma(1, b[t & 1], cv[t & 1]);
-            if (t > 0) {
-                epilogue(2, tile0 + t - 1);
-                epilogue(3, tile0 + t - 1);
-            }
-            // issue order of this half: one MFMA, one LDS read of the next tile, three epilogue instructions, ...
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (t + 1 < kTilesPerStep) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (t > 0) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            }
-            mma(2, b[t & 1], cv[t & 1]);
-            mma(3, b[t & 1], cv[t & 1]);
-            epilogue(0, tile0 + t);
-            epilogue(1, tile0 + t);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            }
-        }
-        pend_tile = tile0 + kTilesPerStep - 1;
-        __syncthreads();
-    }
-    epilogue(2, pend_tile);
-    epilogue(3, pend_tile);
-
-#pragma unroll
-    for (int rb = 0; rb < kQueryRB; ++rb) {
-        // lanes l and l + 32 saw disjoint 16-row groups of every tile for the same query row
-        const int o1 = __shfl_xor(k1[rb], 32);
-        const int o2 = __shfl_xor(k2[rb], 32);
-        const int ot = __shfl_xor(kt[rb], 32);
-        const bool other = o1 < k1[rb] || (o1 == k1[rb] && ot < kt[rb]);
-        const int y1 = min(k1[rb], o1);
-        const int tl = other ? ot : kt[rb];
-        const int y2 = min(max(k1[rb], o1), min(k2[rb], o2));
-        if (half == 0) {
-            const int grow = (qtile + rb) * 32 + lane5;
-            const size_t o = pw.row_off + (size_t)it.chunk * pw.nA_pad + grow;
-            rr_y1[o] = y1;
-            rr_tile[o] = tl;
-            rr_k2[o] = y2;
-        }
-    }
-}
-
-// ---- 1c. the same pass on v_mfma_i32_16x16x64_i8 (experimental) ------------------------------
+// The pass runs on v_mfma_i32_16x16x64_i8: on the same loop the chip sustains about 10 % more operations per
+// second with it than with 32x32x32 (it holds a higher clock), measured on this kernel as 10.8 against 11.9 ms.
 // A wave's 128 query rows are 8 column blocks of 16 (lane l: column l & 15); a 32-row tile is 2 row blocks
 // of 16, K = 128 two steps of 64 (lane quarter q = l >> 4 holds k = 64 c + 16 q .. + 15 of both operands,
 // and accumulator registers 0..3 hold rows 4 q .. 4 q + 3 of the row block).  Operands are read out of the
 // same fragment-major arrays: bytes k = 32 s + 16 h .. + 15 of row r of a tile lie at s * 1024 + (h * 32 + r) * 16.
-__global__ __launch_bounds__(kQueryWaves * 64, 2)
-void sift_query_tile16_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ items,
+__global__ __launch_bounds__(kQueryWaves * 64, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ items,
                               int32_t* __restrict__ rr_y1, int32_t* __restrict__ rr_tile,
                               int32_t* __restrict__ rr_k2)
 {
@@ -515,8 +371,54 @@ void sift_query_tile16_kernel(const SiftPair* __restrict__ pairs, const SiftItem
 #pragma unroll
     for (int cb = 0; cb < kCB; ++cb) { k1[cb] = kYPad; k2[cb] = kYPad; kt[cb] = 0; }
 
+    // Software pipeline in program order, pinned by scheduling barriers (nothing moves across one):
+    //   * column blocks go in pairs: eight MFMAs (first k-step of both row blocks of both column blocks, then
+    //     the second k-step), so an accumulator is read again four MFMAs after it was written;
+    //   * behind every MFMA go two instructions of the epilogue of the PREVIOUS pair, whose accumulators were
+    //     finished at least four MFMAs ago, and, with the first six MFMAs of a tile, one LDS read of the
+    //     operands and constants of the next tile.
+    // zp of pair 3 starts as "nothing": its first (pending) epilogue changes no state.
+    v4i z[kCB][2];
+    z[6][0] = z[6][1] = z[7][0] = z[7][1] = v4i{kYPad, kYPad, kYPad, kYPad};
+    int pend_tile = 0;
+    int mm[2];   // running minima of the pair whose epilogue is in progress
+
+    auto epi = [&](int stage, int cb0, int tileno) {
+        // the empty volatile statements keep each piece where it is written: being pure arithmetic whose
+        // results are needed only at the end, the pieces would otherwise all sink behind the step barrier
+        if (stage < 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int cb = cb0 + u;
+                if (stage == 0) mm[u] = min(min(z[cb][0][0], z[cb][0][1]), min(z[cb][0][2], z[cb][0][3]));
+                else mm[u] = min(min(mm[u], z[cb][1][0]), min(min(z[cb][1][1], z[cb][1][2]), z[cb][1][3]));
+                asm volatile("" : "+v"(mm[u]));
+            }
+        } else {
+            // one column block per piece, four instructions whose order is the compiler's (the compare and the
+            // select that reads its mask want other instructions between them)
+            const int u = stage - 2, cb = cb0 + u;
+            const int m = mm[u], b1 = k1[cb];
+            k2[cb] = max(min(b1, k2[cb]), min(max(b1, k2[cb]), m));   // v_med3_i32: the runner-up of {k1, k2, m}
+            kt[cb] = m < b1 ? tileno : kt[cb];                          // strict: the first tile that holds the minimum
+            k1[cb] = min(b1, m);
+            asm volatile("" : "+v"(k2[cb]), "+v"(kt[cb]), "+v"(k1[cb]));
+        }
+    };
+
     stage_step<kQueryWaves>(smem, 0, Bsrc, Csrc, wave);
     __syncthreads();
+    v4i a[2][2][2], cv[2][2];   // [tile parity][row block][k-step]
+    {
+        const char* tile = smem + lane_off;
+        const int* ctile = reinterpret_cast<const int*>(smem + 2 * kLdsTile) + quad * 4;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            a[0][rb][0] = *reinterpret_cast<const v4i*>(tile + rb * 256);
+            a[0][rb][1] = *reinterpret_cast<const v4i*>(tile + rb * 256 + 2048);
+            cv[0][rb] = *reinterpret_cast<const v4i*>(ctile + rb * 16);
+        }
+    }
 
     for (int st = 0; st < nsteps; ++st) {
         const int cur = st & 1;
@@ -525,33 +427,57 @@ void sift_query_tile16_kernel(const SiftPair* __restrict__ pairs, const SiftItem
         const char* Bt = smem + cur * kLdsTile + lane_off;
         const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm) + quad * 4;
         const int tile0 = (c0 >> 5) + st * kTilesPerStep;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < kTilesPerStep; ++t) {
-            const char* tile = Bt + t * 4096;
-            v4i a[2][2], cv[2];
+            const int p = t & 1, q = p ^ 1;
+            // where tile t + 1 lies; after the last tile of a step, the first tile of the next step's buffer is
+            // read behind the barrier below instead
+            const char* nt = Bt + (t + 1) * 4096;
+            const int* nc = nl + (t + 1) * 32;
+            const bool pre = t + 1 < kTilesPerStep;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                a[rb][0] = *reinterpret_cast<const v4i*>(tile + rb * 256);
-                a[rb][1] = *reinterpret_cast<const v4i*>(tile + rb * 256 + 2048);
-                cv[rb] = *reinterpret_cast<const v4i*>(nl + t * 32 + rb * 16);
-            }
+            for (int pr = 0; pr < 4; ++pr) {
+                const int cb = 2 * pr;
+                const int ecb = pr == 0 ? 6 : cb - 2;
+                const int etile = pr == 0 ? (t == 0 ? pend_tile : tile0 + t - 1) : tile0 + t;
 #pragma unroll
-            for (int cb = 0; cb < kCB; ++cb) {
-                v4i z0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0][0], pf[cb][0], cv[0], 0, 0, 0);
-                v4i z1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1][0], pf[cb][0], cv[1], 0, 0, 0);
-                z0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0][1], pf[cb][1], z0, 0, 0, 0);
-                z1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1][1], pf[cb][1], z1, 0, 0, 0);
-                int m = min(min(z0[0], z0[1]), z0[2]);
-                m = min(min(m, z0[3]), z1[0]);
-                m = min(min(m, z1[1]), z1[2]);
-                m = min(m, z1[3]);
-                k2[cb] = med3i(k1[cb], k2[cb], m);
-                kt[cb] = m < k1[cb] ? tile0 + t : kt[cb];
-                k1[cb] = min(k1[cb], m);
+                for (int i = 0; i < 8; ++i) {
+                    const int u = (i >> 1) & 1, rb = i & 1, ks = i >> 2;
+                    z[cb + u][rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[p][rb][ks], pf[cb + u][ks],
+                                                                          ks == 0 ? cv[p][rb] : z[cb + u][rb], 0, 0, 0);
+                    if (pr == 0 && pre) {
+                        // behind the MFMA, not in front of it: the wait for this tile's operands in front of its
+                        // first MFMA would otherwise also wait for the read just issued
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (i == 0) a[q][0][0] = *reinterpret_cast<const v4i*>(nt);
+                        if (i == 1) a[q][1][0] = *reinterpret_cast<const v4i*>(nt + 256);
+                        if (i == 2) a[q][0][1] = *reinterpret_cast<const v4i*>(nt + 2048);
+                        if (i == 3) a[q][1][1] = *reinterpret_cast<const v4i*>(nt + 256 + 2048);
+                        if (i == 4) cv[q][0] = *reinterpret_cast<const v4i*>(nc);
+                        if (i == 5) cv[q][1] = *reinterpret_cast<const v4i*>(nc + 16);
+                    }
+                    if ((i & 1) == 1) epi(i >> 1, ecb, etile);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
+        pend_tile = tile0 + kTilesPerStep - 1;
         __syncthreads();
+        // the next step's first tile, now that the barrier has made it visible
+        if (st + 1 < nsteps) {
+            const char* tile = smem + (cur ^ 1) * kLdsTile + lane_off;
+            const int* ctile = reinterpret_cast<const int*>(smem + 2 * kLdsTile + (cur ^ 1) * kLdsNorm) + quad * 4;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                a[0][rb][0] = *reinterpret_cast<const v4i*>(tile + rb * 256);
+                a[0][rb][1] = *reinterpret_cast<const v4i*>(tile + rb * 256 + 2048);
+                cv[0][rb] = *reinterpret_cast<const v4i*>(ctile + rb * 16);
+            }
+        }
     }
+#pragma unroll
+    for (int stage = 0; stage < 4; ++stage) epi(stage, 6, pend_tile);
 
 #pragma unroll
     for (int cb = 0; cb < kCB; ++cb) {
@@ -580,14 +506,6 @@ void sift_query_tile16_kernel(const SiftPair* __restrict__ pairs, const SiftItem
 void launch_sift_query_tile(const SiftPair* pairs, const SiftItem* items, int nitems,
                             int32_t* rr_y1, int32_t* rr_tile, int32_t* rr_k2, hipStream_t s)
 {
-    static const bool use16 = getenv("VSM_QT16") != nullptr;
-    if (use16) {
-        static DeviceFlags attr16;
-        ensure_dynamic_lds(attr16, reinterpret_cast<const void*>(sift_query_tile16_kernel), kLdsStream);
-        hipLaunchKernelGGL(sift_query_tile16_kernel, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
-                           pairs, items, rr_y1, rr_tile, rr_k2);
-        return;
-    }
     static DeviceFlags attr_set;   // the attribute is per device
     ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(sift_query_tile_kernel), kLdsStream);
     hipLaunchKernelGGL(sift_query_tile_kernel, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
