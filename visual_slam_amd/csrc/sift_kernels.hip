@@ -481,8 +481,9 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
 
 #pragma unroll
     for (int cb = 0; cb < kCB; ++cb) {
-        // the four lane quarters saw disjoint 8-row groups of every tile for the same query row
-        int y1 = k1[cb], y2 = k2[cb], tl = kt[cb];
+        // the four lane quarters saw disjoint 8-row groups of every tile for the same query row; what goes on to
+        // the resolve pass is the winner's GROUP: tile * 4 + lane quarter (rows 4 q .. 4 q + 3 of both row blocks)
+        int y1 = k1[cb], y2 = k2[cb], tl = kt[cb] * 4 + quad;
 #pragma unroll
         for (int d = 16; d <= 32; d <<= 1) {
             const int o1 = __shfl_xor(y1, d);
@@ -671,55 +672,21 @@ __device__ __forceinline__ bool ratio_ok(const MatchRule& rule, long long d1, lo
     return rule.num2 <= 0 || d1 * rule.den2 < d2 * rule.num2;
 }
 
-// minimum over each row of 16 lanes, valid in all 16 (four DPP steps, no LDS round trip)
-__device__ __forceinline__ int row16_min(int v)
+// minimum over each group of 8 lanes, valid in all 8 (three DPP steps, no LDS round trip)
+__device__ __forceinline__ int group8_min(int v)
 {
     v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
     v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));   // row_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));   // row_half_mirror: lane k <-> 7 - k
     return v;
 }
 
-// The tests of one candidate once its tile has been evaluated (wave-uniform values: scalar unit).
-// best / second: packed (x * 32 + row) minimum of the tile and the minimum without that row.
-__device__ __forceinline__ void resolve_decide(const MatchRule& rule, const SiftCandidates& cand, int p, int c, size_t o,
-                                               int tl, int y1, int y2, long long na, int best, int second, bool lane0)
-{
-    const int r1 = best & 31, x1 = best >> 5;
-    const long long d1 = (long long)x1 + na;
-    bool amb = y2 == y1 || (x1 >> 1) != y1;   // minimum tied with another group: the nearest row may lie there
-    bool pass = false;
-    if (!amb) {
-        const bool has_in = second != INT32_MAX, has_out = y2 < kYPad;
-        bool pr = true;
-        if (has_in || has_out) {
-            const long long in_x = has_in ? (long long)(second >> 5) : INT64_MAX / 4;
-            const long long out_lo = has_out ? 2ll * y2 : INT64_MAX / 4;
-            const bool pa = ratio_ok(rule, d1, min(in_x, out_lo) + na);
-            const bool pb = ratio_ok(rule, d1, min(in_x, out_lo + 1) + na);
-            if (pa != pb) amb = true;   // the parity bit of the runner-up decides
-            pr = pa;
-        }
-        pass = pr && (rule.max_dist < 0 || d1 <= rule.max_dist);
-    }
-    if (lane0) {
-        if (amb) {
-            const int k = atomicAdd(cand.rescan_count, 1);
-            cand.rescan_list[k] = make_int2(p, c);
-            cand.j1[o] = -1;
-        } else {
-            cand.j1[o] = pass ? tl * 32 + r1 : -1;
-            cand.d1[o] = (int)d1;
-        }
-    }
-}
-
-// Half a wave per candidate (lane = row of its tile, the whole 128-byte dot product per lane): the 32 exact
-// distances of the tile give the nearest row (lowest row among equal distances), the exact d1 and the
-// runner-up inside the tile; with the runner-up outside known up to its parity bit the tests are decided
-// unless that bit matters or the minimum is tied with another group.  The reductions are DPP steps and
-// lane reads, the decision runs on the scalar unit.
+// Eight lanes per candidate, lane k = row k of the winner's 8-row group (rows 4 q .. 4 q + 3 of both 16-row
+// blocks of its tile), the whole 128-byte dot product per lane: the 8 exact distances give the nearest row
+// (lowest row among equal distances), the exact d1 and the runner-up inside the group; every row outside the
+// group has y >= y2 with equality somewhere, i.e. the runner-up outside is 2 y2 or 2 y2 + 1.  The tests are
+// decided unless that parity bit matters or the minimum is tied with another group (y2 == y1): those
+// candidates go to the rescan pass.  Candidate records are read 64 at a time (lane k: the k-th of the batch).
 constexpr int kResolveWaves = 4;
 __global__ __launch_bounds__(kResolveWaves * 64)
 void sift_resolve_kernel(const SiftPair* __restrict__ pairs, int slices, MatchRule rule, SiftCandidates cand)
@@ -728,31 +695,31 @@ void sift_resolve_kernel(const SiftPair* __restrict__ pairs, int slices, MatchRu
     const int p = item / slices, sl = item % slices;
     const SiftPair pw = pairs[p];
     const int ncand = cand.count[p];
-    const int lane = threadIdx.x & 63, r = lane & 31, hw = lane >> 5;
+    const int lane = threadIdx.x & 63, k8 = lane & 7, grp = lane >> 3;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int stride = slices * kResolveWaves;
     const int8_t VSM_GLB* fragA = (const int8_t VSM_GLB*)pw.fragA;
     const int8_t VSM_GLB* fragB = (const int8_t VSM_GLB*)pw.fragB;
     const int32_t VSM_GLB* nrmA = (const int32_t VSM_GLB*)pw.nrmA;
     const int32_t VSM_GLB* nrmB = (const int32_t VSM_GLB*)pw.nrmB;
-    // A wave takes candidates first, first + stride, ...  Their records are read 64 at a time (lane k: the
-    // k-th of the batch), so that a round -- two candidates, one per half wave -- costs one round trip to
-    // memory (query row + tile), not two.
+    // a wave takes candidates first, first + stride, ...
     const int first = sl * kResolveWaves + wave;
     for (int base = first; base < ncand; base += 64 * stride) {
         const int cl = base + lane * stride;
         const bool live = cl < ncand;
         const size_t ol = pw.out0_off + (live ? cl : base);
-        const int rec_i = cand.i0[ol], rec_t = cand.j1[ol], rec_y1 = cand.d1[ol], rec_y2 = cand.aux[ol];
+        const int rec_i = cand.i0[ol], rec_g = cand.j1[ol], rec_y1 = cand.d1[ol], rec_y2 = cand.aux[ol];
         const int rec_na = nrmA[rec_i] >> 8;
         const int nb = min(64, (ncand - base + stride - 1) / stride);   // candidates in this batch
-        for (int k = 0; k < nb; k += 2) {
-            const bool two = k + 1 < nb;
-            const int kb = two ? k + 1 : k;
-            // wave-uniform copies of both candidates' records; each half works on its own
-            const int iA = __builtin_amdgcn_readlane(rec_i, k), iB = __builtin_amdgcn_readlane(rec_i, kb);
-            const int tA = __builtin_amdgcn_readlane(rec_t, k), tB = __builtin_amdgcn_readlane(rec_t, kb);
-            const int i = hw ? iB : iA, tl = hw ? tB : tA;
+        for (int k0 = 0; k0 < nb; k0 += 8) {
+            const int k = k0 + grp;              // this group's candidate of the batch
+            const bool have = k < nb;
+            const int src = have ? k : k0;
+            const int i = __shfl(rec_i, src), g = __shfl(rec_g, src);
+            const int y1 = __shfl(rec_y1, src), y2 = __shfl(rec_y2, src);
+            const long long na = __shfl(rec_na, src);
+            const int tl = g >> 2, quad = g & 3;
+            const int r = (k8 >> 2) * 16 + quad * 4 + (k8 & 3);     // row of the tile
             const int8_t VSM_GLB* q = fragA + (size_t)(i >> 5) * kTileBytes + (i & 31) * 16;
             const int8_t VSM_GLB* t = fragB + (size_t)tl * kTileBytes + r * 16;
             int dot = 0;
@@ -764,22 +731,39 @@ void sift_resolve_kernel(const SiftPair* __restrict__ pairs, int slices, MatchRu
                                 *reinterpret_cast<const v4i VSM_GLB*>(t + s * 1024 + h * 512), dot);
             }
             const int row = tl * 32 + r;
-            // |x| < 2^23: value and row in one key
-            const int key = row < pw.nB ? ((nrmB[row] >> 8) - 2 * dot) * 32 + r : INT32_MAX;
-            const int m = row16_min(key);
-            const int bestA = min(__builtin_amdgcn_readlane(m, 0), __builtin_amdgcn_readlane(m, 16));
-            const int bestB = min(__builtin_amdgcn_readlane(m, 32), __builtin_amdgcn_readlane(m, 48));
-            const int mine = hw ? bestB : bestA;
-            const int m2 = row16_min(r == (mine & 31) ? INT32_MAX : key);
-            const int secA = min(__builtin_amdgcn_readlane(m2, 0), __builtin_amdgcn_readlane(m2, 16));
-            const int secB = min(__builtin_amdgcn_readlane(m2, 32), __builtin_amdgcn_readlane(m2, 48));
-            const int cA = base + k * stride;
-            resolve_decide(rule, cand, p, cA, pw.out0_off + cA, tA, __builtin_amdgcn_readlane(rec_y1, k),
-                           __builtin_amdgcn_readlane(rec_y2, k), __builtin_amdgcn_readlane(rec_na, k), bestA, secA, lane == 0);
-            if (two)
-                resolve_decide(rule, cand, p, cA + stride, pw.out0_off + cA + stride, tB, __builtin_amdgcn_readlane(rec_y1, kb),
-                               __builtin_amdgcn_readlane(rec_y2, kb), __builtin_amdgcn_readlane(rec_na, kb), bestB, secB,
-                               lane == 0);
+            // |x| < 2^23: value and position in the group in one key (positions ascend with the rows)
+            const int key = row < pw.nB ? ((nrmB[row] >> 8) - 2 * dot) * 8 + k8 : INT32_MAX;
+            const int best = group8_min(key);
+            const int second = group8_min(k8 == (best & 7) ? INT32_MAX : key);
+            const int kb = best & 7, x1 = best >> 3;
+            const long long d1 = (long long)x1 + na;
+            bool amb = y2 == y1 || (x1 >> 1) != y1;   // minimum tied with another group: the nearest row may lie there
+            bool pass = false;
+            if (!amb) {
+                const bool has_in = second != INT32_MAX, has_out = y2 < kYPad;
+                bool pr = true;
+                if (has_in || has_out) {
+                    const long long in_x = has_in ? (long long)(second >> 3) : INT64_MAX / 4;
+                    const long long out_lo = has_out ? 2ll * y2 : INT64_MAX / 4;
+                    const bool pa = ratio_ok(rule, d1, min(in_x, out_lo) + na);
+                    const bool pb = ratio_ok(rule, d1, min(in_x, out_lo + 1) + na);
+                    if (pa != pb) amb = true;   // the parity bit of the runner-up decides
+                    pr = pa;
+                }
+                pass = pr && (rule.max_dist < 0 || d1 <= rule.max_dist);
+            }
+            if (have && k8 == 0) {
+                const int c = base + k * stride;
+                const size_t o = pw.out0_off + c;
+                if (amb) {
+                    const int e = atomicAdd(cand.rescan_count, 1);
+                    cand.rescan_list[e] = make_int2(p, c);
+                    cand.j1[o] = -1;
+                } else {
+                    cand.j1[o] = pass ? tl * 32 + (kb >> 2) * 16 + quad * 4 + (kb & 3) : -1;
+                    cand.d1[o] = (int)d1;
+                }
+            }
         }
     }
 }
