@@ -308,6 +308,46 @@ def test_ties_between_chunks_with_merged_chunk_records(matcher):
         matcher.release(s1)
 
 
+def test_mutual_check_spoiled_by_rows_that_are_no_candidates(matcher):
+    """The verify pass looks only at image-0 rows whose own nearest distance does not exceed the largest
+    accepted candidate distance of the pair.  Rows that spoil a candidate's mutual check without being
+    candidates themselves (they fail the ratio test: two train rows equally near) must be among them, as must
+    rows at exactly that distance, and ties in a candidate's column go to the lower image-0 row."""
+    rng = np.random.default_rng(29)
+    a = synth.sift_like(3000, rng)
+    b = synth.sift_like(2600, rng)
+
+    def bump(row, k, amount):
+        out = row.copy()
+        out[k % 128] = out[k % 128] + amount if out[k % 128] <= 255 - amount else out[k % 128] - amount
+        return out
+
+    for k in range(120):
+        j, j2 = 20 * k, 20 * k + 7
+        i, sp = 23 * k + 1, 23 * k + 5          # candidate row and its spoiler (a higher row: only distance decides)
+        a[i] = bump(b[j], k, 3)                  # d(i, j) = 9: passes the ratio test
+        if k % 3 == 0:
+            b[j2] = bump(b[j], k + 1, 1)         # a second train row as near to the spoiler as the first ...
+            a[sp] = bump(b[j], k + 2, 1)         # ... so the spoiler (d = 1 to j, 2 to j2) fails the ratio test itself
+        elif k % 3 == 1:
+            a[sp] = bump(b[j], k + 2, 3)         # the same distance as the candidate, higher row: does not spoil
+        else:
+            a[23 * k] = bump(b[j], k + 2, 3)     # the same distance, LOWER row: takes the column
+    s0, s1 = matcher.upload_u8(a), matcher.upload_u8(b)
+    try:
+        for ratio in ((4, 5), (1, 2)):
+            g0, g1, gd = matcher.match_pair(s0, s1, ratio=ratio[0] / ratio[1], mutual=True, return_dist=True)
+            o0, o1, od = orc.match_u8(a, b, orc.params(ratio, True))
+            np.testing.assert_array_equal(g0, o0)
+            np.testing.assert_array_equal(g1, o1)
+            np.testing.assert_array_equal(gd, od)
+            n0, _, _ = orc.match_u8(a, b, orc.params(ratio, False))
+            assert len(n0) > len(o0) + 30     # the mutual check did reject rows
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)
+
+
 def test_parity_of_the_runner_up_decides(matcher):
     """d1 * den^2 < num^2 * d2 with d2 straddling the boundary: rows built so that the true runner-up
     distance is 2 k or 2 k + 1 around the value where the test flips."""

@@ -559,14 +559,17 @@ void sift_merge_chunks_kernel(const SiftPair* __restrict__ pairs, int32_t* __res
 
 __global__ __launch_bounds__(1024)
 void sift_select_tile_kernel(const SiftPair* __restrict__ pairs,
-                             const int32_t* __restrict__ rr_y1, const int32_t* __restrict__ rr_tile,
+                             int32_t* __restrict__ rr_y1, const int32_t* __restrict__ rr_tile,
                              const int32_t* __restrict__ rr_k2, int merged, MatchRule rule, SiftCandidates cand)
 {
     __shared__ int wsum[16];
     __shared__ int base_s;
     const SiftPair pw = pairs[blockIdx.x];
     const int tid = threadIdx.x;
-    if (tid == 0) base_s = 0;
+    if (tid == 0) {
+        base_s = 0;
+        cand.dmax[blockIdx.x] = INT32_MIN;
+    }
     if (blockIdx.x == 0 && tid == 0) *cand.rescan_count = 0;
     __syncthreads();
 
@@ -592,6 +595,12 @@ void sift_select_tile_kernel(const SiftPair* __restrict__ pairs,
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r) merge_chunk_row(e1[r], et[r], e2[r], y1[r], tl[r], y2[r]);
+            }
+            if (nchunks > 1) {
+                // the merged half-distances stay in chunk 0's records: sift_verify_rows_kernel reads them
+                int32_t* dst = rr_y1 + pw.row_off + ib;
+                *reinterpret_cast<int4*>(dst) = make_int4(y1[0], y1[1], y1[2], y1[3]);
+                *reinterpret_cast<int4*>(dst + 4) = make_int4(y1[4], y1[5], y1[6], y1[7]);
             }
         }
         unsigned okbits = 0;
@@ -762,6 +771,7 @@ void sift_resolve_kernel(const SiftPair* __restrict__ pairs, int slices, MatchRu
                 } else {
                     cand.j1[o] = pass ? tl * 32 + (kb >> 2) * 16 + quad * 4 + (kb & 3) : -1;
                     cand.d1[o] = (int)d1;
+                    if (pass) atomicMax(&cand.dmax[p], (int)d1);
                 }
             }
         }
@@ -810,8 +820,48 @@ void sift_rescan_kernel(const SiftPair* __restrict__ pairs, MatchRule rule, Sift
         if (lane == 0) {
             cand.j1[o] = pass ? wrow : -1;
             cand.d1[o] = (int)d1;
+            if (pass) atomicMax(&cand.dmax[pc.x], (int)d1);
         }
     }
+}
+
+// The image-0 rows that can matter to the mutual check of a pair (see SiftCandidates::dmax), in ascending order.
+__global__ __launch_bounds__(1024)
+void sift_verify_rows_kernel(const SiftPair* __restrict__ pairs, const int32_t* __restrict__ rr_y1, SiftCandidates cand)
+{
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const SiftPair pw = pairs[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    const long long dmax = cand.dmax[blockIdx.x];
+    constexpr int R = 4;
+    for (int i0 = 0; i0 < pw.nA; i0 += 1024 * R) {
+        const int ib = i0 + tid * R;
+        unsigned okbits = 0;
+        if (ib < pw.nA) {
+            const int4 y = *reinterpret_cast<const int4*>(rr_y1 + pw.row_off + ib);
+            const int4 na = *reinterpret_cast<const int4*>(pw.nrmA + ib);
+            const int yy[R] = {y.x, y.y, y.z, y.w}, nn[R] = {na.x, na.y, na.z, na.w};
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (ib + r < pw.nA && yy[r] < kYPad && 2ll * yy[r] + (nn[r] >> 8) <= dmax) okbits |= 1u << r;
+        }
+        int slot = block_compact_range(__popc(okbits), wsum, &base_s);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((okbits >> r) & 1u) cand.vrows[pw.out0_off + slot++] = ib + r;
+    }
+    __syncthreads();
+    if (tid == 0) cand.nvrows[blockIdx.x] = base_s;
+}
+
+void launch_sift_verify_rows(const SiftPair* pairs, int npairs, const int32_t* rr_y1, SiftCandidates cand,
+                             hipStream_t s)
+{
+    if (npairs <= 0) return;
+    hipLaunchKernelGGL(sift_verify_rows_kernel, dim3(npairs), dim3(1024), 0, s, pairs, rr_y1, cand);
 }
 
 void launch_sift_resolve(const SiftPair* pairs, int npairs, int max_rows, MatchRule rule, SiftCandidates cand,
@@ -852,7 +902,10 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
     const SiftItem it = vitems[w / nsplit];
     const int part = w % nsplit;
     const SiftPair pw = pairs[it.pair];
-    const int allsteps = pw.nA_pad / kStepRows;
+    // with a row list the streamed set is the listed rows of image 0, gathered step by step
+    const int32_t* __restrict__ vrows = cand.vrows ? cand.vrows + pw.out0_off : nullptr;
+    const int nv = vrows ? cand.nvrows[it.pair] : pw.nA_pad;
+    const int allsteps = (nv + kStepRows - 1) / kStepRows;
     const int st0 = (int)((long long)allsteps * part / nsplit), st1 = (int)((long long)allsteps * (part + 1) / nsplit);
     if (st0 == st1) continue;
     const int ncand = cand.count[it.pair];
@@ -876,13 +929,34 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
 #pragma unroll
     for (int rb = 0; rb < kVerifyRB; ++rb) { bestd[rb] = kDistPad; bestrow[rb] = INT32_MAX; }
 
-    stage_step<kVerifyWaves>(smem, 0, Asrc + (size_t)st0 * kLdsTile, Nsrc + st0 * kStepRows, wave);
+    // One step of listed rows: every lane fetches the 16-byte pieces of its own row of the wave's two tiles out
+    // of whichever tile of image 0 holds it (LDS-DMA takes a global address per lane), and the packed norm of
+    // the row at its position of the step, with the position as the row code.
+    auto stage_rows = [&](int buf, int st) {
+        char* dst = smem + buf * kLdsTile + wave * (kLdsTile / kVerifyWaves);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int pos = st * kStepRows + (wave * 2 + tt) * 32 + lane5;
+            const int row = pos < nv ? vrows[pos] : 0;
+            const int8_t* src = pw.fragA + (size_t)(row >> 5) * kTileBytes + (half * 32 + (row & 31)) * 16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dma16(src + s * 1024, dst + (tt * 4 + s) * 1024);
+        }
+        const int pos = st * kStepRows + wave * 64 + lane;
+        const int code = pos < nv ? (pw.nrmA[vrows[pos]] & ~255) : kNormPad;
+        reinterpret_cast<int*>(smem + 2 * kLdsTile + buf * kLdsNorm)[wave * 64 + lane] = code | (pos & 255);
+    };
+    auto stage = [&](int buf, int st) {
+        if (vrows) stage_rows(buf, st);
+        else stage_step<kVerifyWaves>(smem, buf, Asrc + (size_t)st * kLdsTile, Nsrc + st * kStepRows, wave);
+    };
+
+    stage(0, st0);
     __syncthreads();
 
     for (int st = st0; st < st1; ++st) {
         const int cur = (st - st0) & 1;
-        if (st + 1 < st1)
-            stage_step<kVerifyWaves>(smem, cur ^ 1, Asrc + (size_t)(st + 1) * kLdsTile, Nsrc + (st + 1) * kStepRows, wave);
+        if (st + 1 < st1) stage(cur ^ 1, st + 1);
         const char* At = smem + cur * kLdsTile + lane * 16;
         const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm);
         int m[kVerifyRB];
@@ -935,9 +1009,12 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
             bestd[rb] = od;
             bestrow[rb] = orow;
         }
-        if (half == 0 && ci[rb] < ncand)
+        if (half == 0 && ci[rb] < ncand) {
+            // positions of the row list ascend with the rows: the lowest position is the lowest row
+            const int row = vrows && bestrow[rb] < nv ? vrows[bestrow[rb]] : bestrow[rb];
             atomicMin(&cand.vbest[pw.out0_off + ci[rb]],
-                      ((unsigned long long)((unsigned)bestd[rb] ^ 0x80000000u) << 32) | (unsigned)bestrow[rb]);   // sign bit flipped: the distances are relative (the candidate's own norm is left out) and may be negative
+                      ((unsigned long long)((unsigned)bestd[rb] ^ 0x80000000u) << 32) | (unsigned)row);
+        }   // sign bit flipped: the distances are relative (the candidate's own norm is left out) and may be negative
     }
     }   // next work item (the last step's barrier separates it from this one's LDS reads)
 }

@@ -276,8 +276,9 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     HIPCHK(c, c->d_rr1.ensure(rows * 4));
     HIPCHK(c, c->d_rrj.ensure(rows * 4));
     HIPCHK(c, c->d_rr2.ensure(rows * 4));
-    // vbest (8) + i0, j1, d1, aux (4 each) + rescan list (8) per row, then per-pair counts and the rescan counter
-    HIPCHK(c, c->d_cand.ensure(out0 * 32 + sizeof(int32_t) * (std::max(npairs, 1) + 16)));
+    // vbest (8) + i0, j1, d1, aux (4 each) + rescan list (8) + row list of the verify pass (4) per row, then
+    // per-pair counts, largest accepted distances and row-list lengths, and the rescan counter
+    HIPCHK(c, c->d_cand.ensure(out0 * 36 + sizeof(int32_t) * (3 * std::max(npairs, 1) + 16)));
     // The tile-minimum query pass leaves row and exact distances to a resolve pass over the candidates: it
     // pays when the ratio test keeps the candidates few, and it does not produce the raw 2-NN outputs.
     const bool tile_path = c->u8_mode == 0 && !o.packed_only && rule.num2 > 0 && !o.want_knn;
@@ -332,8 +333,16 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
         cand.d1 = cand.j1 + out0;
         cand.aux = cand.d1 + out0;
         cand.rescan_list = reinterpret_cast<int2*>(cand.aux + out0);
-        cand.count = reinterpret_cast<int32_t*>(cand.rescan_list + out0);
-        cand.rescan_count = cand.count + std::max(npairs, 1);
+        int32_t* row_list = reinterpret_cast<int32_t*>(cand.rescan_list + out0);
+        cand.count = row_list + out0;
+        int32_t* dmax = cand.count + std::max(npairs, 1);
+        int32_t* nvrows = dmax + std::max(npairs, 1);
+        cand.rescan_count = nvrows + std::max(npairs, 1);
+        if (tile_path) {   // the packed path has no bound on the rows that matter: its verify pass streams them all
+            cand.dmax = dmax;
+            cand.vrows = row_list;
+            cand.nvrows = nvrows;
+        }
         SiftOutputs out{};
         out.slot_i0 = c->d_slot0.as<int32_t>();
         out.slot_i1 = c->d_slot1.as<int32_t>();
@@ -357,6 +366,7 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
             launch_sift_select_tile(c->d_pairs.as<SiftPair>(), npairs, max_rows, max_chunks, c->d_rr1.as<int32_t>(),
                                     c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, c->stream);
             launch_sift_resolve(c->d_pairs.as<SiftPair>(), npairs, max_rows, rule, cand, c->stream);
+            if (nvitems) launch_sift_verify_rows(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(), cand, c->stream);
         } else {
             launch_sift_select(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(),
                                c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, out, c->stream);

@@ -73,12 +73,20 @@ struct SiftCandidates {
     // nearest image-0 row of column j1 as (distance with its sign bit flipped << 32 | row): set to all ones by the select pass,
     // lowered by the verify pass with an atomic minimum (lowest row among equal distances)
     unsigned long long* vbest;
-    // tile-minimum path only.  Between its select and resolve passes j1 holds the 32-row train tile of the
-    // nearest row, d1 its half-distance y1, aux the smallest half-distance outside that tile's lane group;
+    // tile-minimum path only.  Between its select and resolve passes j1 holds the 8-row group of the nearest
+    // row (tile * 4 + lane quarter), d1 its half-distance y1, aux the smallest half-distance outside that group;
     // the resolve pass replaces j1 by the row (-1: rejected) and d1 by the exact squared distance.
     int32_t* aux;
-    int32_t* rescan_count;   // candidates the resolve pass could not settle from one tile ...
+    int32_t* rescan_count;   // candidates the resolve pass could not settle from one group ...
     int2* rescan_list;       // ... as (pair, candidate); the rescan pass searches the whole train set for them
+    // tile-minimum path only: the image-0 rows the verify pass has to look at.  dmax[pair] = the largest exact
+    // distance of a candidate that passed its tests; a row whose own nearest distance (at least
+    // 2 y1 + |a|^2) exceeds it is farther than that from EVERY train row, so it cannot come before any
+    // candidate in any candidate's column.  vrows (at out0_off, ascending) lists the other rows, nvrows[pair]
+    // counts them.  NULL in the packed path: the verify pass then streams all of image 0.
+    int32_t* dmax;
+    int32_t* vrows;
+    int32_t* nvrows;
 };
 
 struct SiftOutputs {
@@ -185,6 +193,10 @@ void launch_sift_query_tile(const SiftPair* pairs, const SiftItem* items, int ni
                             int32_t* rr_y1, int32_t* rr_tile, int32_t* rr_k2, hipStream_t s);
 void launch_sift_select_tile(const SiftPair* pairs, int npairs, int max_rows, int max_chunks, int32_t* rr_y1,
                              int32_t* rr_tile, int32_t* rr_k2, MatchRule rule, SiftCandidates cand, hipStream_t s);
+// After the resolve pass: cand.vrows / cand.nvrows from the merged half-distances the select pass left in
+// chunk 0's records of rr_y1.
+void launch_sift_verify_rows(const SiftPair* pairs, int npairs, const int32_t* rr_y1, SiftCandidates cand,
+                             hipStream_t s);
 void launch_sift_resolve(const SiftPair* pairs, int npairs, int max_rows, MatchRule rule, SiftCandidates cand,
                          hipStream_t s);
 // chunk merge + distance/ratio tests -> candidate lists (+ raw 2-NN outputs)
