@@ -119,6 +119,8 @@ struct vsm_ctx {
         DevBuf d_offsets, d_tight0, d_tight1;
         HostBuf h_pairs, h_items, h_off;
         hipEvent_t packed = nullptr;
+        hipEvent_t staged = nullptr;    // the slot's pinned staging buffers have been copied to the device
+        bool staged_recorded = false;
         // timing brackets of the submission that last used this slot
         hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
         bool ev_valid = false, ev_verify_valid = false;
@@ -301,13 +303,17 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
         HIPCHK(c, c->d_knn1.ensure(out0 * 4));
         HIPCHK(c, c->d_knn2.ensure(out0 * 4));
     }
-    // the pinned staging buffers may still feed a previous copy
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // The slot's pinned staging buffers may still feed the copy of the submission that last used them: wait for
+    // that copy, not for the stream (a submission queued behind another one would otherwise leave the chip idle
+    // between the two while the host catches up).
+    if (c->R().staged_recorded) HIPCHK(c, hipEventSynchronize(c->R().staged));
     if (npairs) memcpy(c->R().h_pairs.p, pl.pairs.data(), sizeof(SiftPair) * npairs);
     if (nitems) memcpy(c->R().h_items.p, pl.items.data(), sizeof(SiftItem) * nitems);
     if (npairs) HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->R().h_pairs.p, sizeof(SiftPair) * npairs, hipMemcpyHostToDevice, c->stream));
     if (nitems)
         HIPCHK(c, hipMemcpyAsync(c->d_items.p, c->R().h_items.p, sizeof(SiftItem) * nitems, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->R().staged, c->stream));
+    c->R().staged_recorded = true;
 
     c->R().ev_valid = false;
     c->timing_slot = c->rs;
@@ -466,7 +472,9 @@ extern "C" vsm_ctx* vsm_create(int device)
         (e = hipEventCreate(&c->slots[1].ev2)) != hipSuccess || (e = hipEventCreate(&c->slots[1].ev3)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->slots[0].packed, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->slots[1].packed, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&c->slots[1].packed, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->slots[0].staged, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->slots[1].staged, hipEventDisableTiming)) != hipSuccess) {
         fail(nullptr, VSM_ENODEV, "stream/event creation: %s", hipGetErrorString(e));
         vsm_destroy(c);   // releases whatever was created
         return nullptr;
@@ -498,6 +506,7 @@ extern "C" void vsm_destroy(vsm_ctx* c)
         r.h_items.release();
         r.h_off.release();
         if (r.packed) (void)hipEventDestroy(r.packed);
+        if (r.staged) (void)hipEventDestroy(r.staged);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->h_small.release();
