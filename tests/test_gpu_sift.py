@@ -348,6 +348,28 @@ def test_mutual_check_spoiled_by_rows_that_are_no_candidates(matcher):
         matcher.release(s1)
 
 
+def test_short_row_list_of_the_mutual_check_on_full_range_bytes(matcher):
+    """Few accepted candidates among full-range random bytes: the mutual check then streams a list of a few
+    rows, and the positions past the end of the list must behave like padding rows whatever the sign of the
+    (zero-point-shifted) products of real rows would be."""
+    rng = np.random.default_rng(31)
+    a = rng.integers(0, 256, (565, 128)).astype(np.uint8)
+    b = rng.integers(0, 256, (5605, 128)).astype(np.uint8)
+    b[rng.choice(5605, 40, replace=False)] = a[rng.choice(565, 40, replace=False)]
+    s0, s1 = matcher.upload_u8(a), matcher.upload_u8(b)
+    try:
+        for cap in (-1, 8510):
+            g0, g1, gd = matcher.match_pair(s0, s1, ratio=0.75, mutual=True, max_dist_sq=cap, return_dist=True)
+            o0, o1, od = orc.match_u8(a, b, orc.params((3, 4), True, max_dist_sq=cap))
+            np.testing.assert_array_equal(g0, o0)
+            np.testing.assert_array_equal(g1, o1)
+            np.testing.assert_array_equal(gd, od)
+            assert len(o0) >= 30
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)
+
+
 def test_parity_of_the_runner_up_decides(matcher):
     """d1 * den^2 < num^2 * d2 with d2 straddling the boundary: rows built so that the true runner-up
     distance is 2 k or 2 k + 1 around the value where the test flips."""

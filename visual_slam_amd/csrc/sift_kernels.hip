@@ -938,7 +938,7 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
         for (int tt = 0; tt < 2; ++tt) {
             const int pos = st * kStepRows + (wave * 2 + tt) * 32 + lane5;
             const int row = pos < nv ? vrows[pos] : 0;
-            const int8_t* src = pw.fragA + (size_t)(row >> 5) * kTileBytes + (half * 32 + (row & 31)) * 16;
+            const int8_t* src = (pos < nv ? pw.fragA + (size_t)(row >> 5) * kTileBytes : cand.zero_tile) + (half * 32 + (row & 31)) * 16;
 #pragma unroll
             for (int s = 0; s < 4; ++s) dma16(src + s * 1024, dst + (tt * 4 + s) * 1024);
         }

@@ -105,6 +105,7 @@ struct vsm_ctx {
     // workspace (grow-only)
     DevBuf d_pairs, d_items, d_rr1, d_rrj, d_rr2, d_colpart, d_cand;
     DevBuf d_slot0, d_slot1, d_slotd, d_counts;
+    DevBuf d_zero_tile;   // kTileBytes of zeros (see SiftCandidates::zero_tile)
     DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_probs, d_geom, d_short;
     // float sets: 0 = bf16 coarse pass + exact re-rank (exact kernel when a survivor list overflows), 1 = exact kernel only
     int f32_mode = 0, last_f32_path = -1;
@@ -281,6 +282,10 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     // vbest (8) + i0, j1, d1, aux (4 each) + rescan list (8) + row list of the verify pass (4) per row, then
     // per-pair counts, largest accepted distances and row-list lengths, and the rescan counter
     HIPCHK(c, c->d_cand.ensure(out0 * 36 + sizeof(int32_t) * (3 * std::max(npairs, 1) + 16)));
+    if (!c->d_zero_tile.p) {
+        HIPCHK(c, c->d_zero_tile.ensure(kTileBytes));
+        HIPCHK(c, hipMemsetAsync(c->d_zero_tile.p, 0, kTileBytes, c->stream));
+    }
     // The tile-minimum query pass leaves row and exact distances to a resolve pass over the candidates: it
     // pays when the ratio test keeps the candidates few, and it does not produce the raw 2-NN outputs.
     const bool tile_path = c->u8_mode == 0 && !o.packed_only && rule.num2 > 0 && !o.want_knn;
@@ -348,6 +353,7 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
             cand.dmax = dmax;
             cand.vrows = row_list;
             cand.nvrows = nvrows;
+            cand.zero_tile = c->d_zero_tile.as<int8_t>();
         }
         SiftOutputs out{};
         out.slot_i0 = c->d_slot0.as<int32_t>();
@@ -493,7 +499,7 @@ extern "C" void vsm_destroy(vsm_ctx* c)
         if (s.nrm) (void)hipFree(s.nrm);
         if (s.shadow) (void)hipFree(s.shadow);
     }
-    DevBuf* bufs[] = {&c->d_pairs, &c->d_items, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart, &c->d_cand,
+    DevBuf* bufs[] = {&c->d_zero_tile, &c->d_pairs, &c->d_items, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart, &c->d_cand,
                       &c->d_slot0, &c->d_slot1, &c->d_slotd, &c->d_counts, &c->d_dense0, &c->d_dense1,
                       &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage, &c->d_coarse,
                       &c->d_probs, &c->d_geom, &c->d_short};

@@ -87,6 +87,9 @@ struct SiftCandidates {
     int32_t* dmax;
     int32_t* vrows;
     int32_t* nvrows;
+    // one 32-row tile of zero operands (kTileBytes): what the positions past the end of a row list stream, so
+    // that their packed keys stay the padding constant (a real row's products would overflow it)
+    const int8_t* zero_tile;
 };
 
 struct SiftOutputs {
