@@ -190,10 +190,10 @@ int check_params(vsm_ctx* c, const vsm_params* p)
     return VSM_OK;
 }
 
-// One submission may use this many bytes of per-row scratch (partial results, candidate and
-// output lists: about 40 bytes per image-0 row).
+// One submission may use this many bytes of per-row scratch (partial results 12 per chunk, candidate records and
+// the verify pass's row list 36, output slots and packed lists 16: about 64 bytes per image-0 row).
 constexpr size_t kDefaultScratchBudget = (size_t)8 << 30;
-constexpr size_t kScratchPerRow = 40;
+constexpr size_t kScratchPerRow = 64;
 
 struct Plan {
     std::vector<SiftPair> pairs;
