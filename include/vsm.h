@@ -106,8 +106,9 @@ int vsm_last_f32_reverse(const vsm_ctx* ctx);
  * index on ties).
  *   VSM_U8_AUTO (default): submissions with a ratio test run the tile-minimum query pass (the matrix
  *     cores produce half-distances directly, each lane keeps the minimum per 32-row tile) and settle row,
- *     exact distance and tests for the few candidates afterwards; everything else (no ratio test, raw
- *     2-NN) runs the packed form.
+ *     exact distance and tests for the few candidates afterwards; their mutual check looks only at the
+ *     image-0 rows near enough to anything to matter.  Everything else (no ratio test, raw 2-NN) runs the
+ *     packed form.
  *   VSM_U8_PACKED: the packed form only (value and row in one key for every distance). */
 enum { VSM_U8_AUTO = 0, VSM_U8_PACKED = 1 };
 int vsm_set_u8_mode(vsm_ctx* ctx, int mode);

@@ -7,7 +7,11 @@
 //
 // Pipeline per submission of image pairs:
 //   1. query pass   (MFMA)  every image-0 row: nearest image-1 row, distance, runner-up distance
+//                            (tile-minimum form: smallest half-distance, the 8-row group holding it, the smallest
+//                            half-distance outside that group)
 //   2. select                distance cap + ratio test -> compact candidate list per pair
+//                            (tile-minimum form: optimistic tests, then resolve / rescan of the candidates: exact
+//                            row, distance and tests; then the list of image-0 rows the mutual check must look at)
 //   3. verify pass  (MFMA)  every candidate's image-1 row: nearest image-0 row (mutual check);
 //                            only the candidates' columns are revisited, not the whole matrix
 //   4. confirm               keep candidates whose nearest image-0 row is the candidate itself
@@ -778,7 +782,7 @@ void sift_resolve_kernel(const SiftPair* __restrict__ pairs, int slices, MatchRu
     }
 }
 
-// The candidates one tile could not settle: exact two nearest over the whole train set, one wave each.
+// The candidates one group could not settle: exact two nearest over the whole train set, one wave each.
 constexpr int kRescanGrid = 512;
 __global__ __launch_bounds__(kResolveWaves * 64)
 void sift_rescan_kernel(const SiftPair* __restrict__ pairs, MatchRule rule, SiftCandidates cand)

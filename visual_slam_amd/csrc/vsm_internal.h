@@ -189,9 +189,10 @@ void launch_sift_plan_single(const SiftPair& sp, SiftPair* pair_out, SiftItem* i
 void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
                        int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, hipStream_t s);
 // Tile-minimum form of the query pass and its follow-ups (ratio-test submissions): per (chunk, query row)
-// the smallest half-distance y1, the 32-row train tile that holds it, and the smallest half-distance outside
-// that tile's lane group; select with optimistic tests (a superset of the final candidates); resolve from the
-// one tile (row, exact distance, exact tests), rescan of the few rows one tile cannot settle.
+// the smallest half-distance y1, the 8-row group of a 32-row train tile that holds it (tile * 4 + lane quarter),
+// and the smallest half-distance outside that group; select with optimistic tests (a superset of the final
+// candidates); resolve from the one group (row, exact distance, exact tests), rescan of the few rows one group
+// cannot settle.
 void launch_sift_query_tile(const SiftPair* pairs, const SiftItem* items, int nitems,
                             int32_t* rr_y1, int32_t* rr_tile, int32_t* rr_k2, hipStream_t s);
 void launch_sift_select_tile(const SiftPair* pairs, int npairs, int max_rows, int max_chunks, int32_t* rr_y1,
