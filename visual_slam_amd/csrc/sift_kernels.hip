@@ -168,6 +168,9 @@ __device__ __forceinline__ void tile_consts(const int* nl_tile, int half, int (&
 constexpr int kQueryWaves = 4;
 constexpr int kQueryRB = kStripRows / (32 * kQueryWaves);
 
+// SECOND = false: the caller has no use for the runner-up distance (no ratio test, no raw 2-NN output); the
+// epilogue is then 1.5 instead of 2.25 vector instructions per distance and rr_d2 receives "none".
+template <bool SECOND>
 __global__ __launch_bounds__(kQueryWaves * 64, 2)
 void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ items,
                        int32_t* __restrict__ rr_d1, int32_t* __restrict__ rr_j1,
@@ -245,10 +248,14 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
                 for (int e = 0; e < 8; ++e) {
                     const int x0 = __mul24(acc[rb][2 * e], negscale) + c[2 * e];
                     const int x1 = __mul24(acc[rb][2 * e + 1], negscale) + c[2 * e + 1];
-                    const int u = med3i(k1[rb], x0, x1);   // runner-up of {k1, x0, x1}
-                    k1[rb] = min3i(k1[rb], x0, x1);
-                    if (e & 1) k2[rb] = min3i(k2[rb], uprev, u);
-                    uprev = u;
+                    if (SECOND) {
+                        const int u = med3i(k1[rb], x0, x1);   // runner-up of {k1, x0, x1}
+                        k1[rb] = min3i(k1[rb], x0, x1);
+                        if (e & 1) k2[rb] = min3i(k2[rb], uprev, u);
+                        uprev = u;
+                    } else {
+                        k1[rb] = min3i(k1[rb], x0, x1);
+                    }
                 }
             }
         }
@@ -259,13 +266,13 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
             const int d = k1[rb] >> 8;
             const int col = c0 + st * kStepRows + (k1[rb] & 255);
             if (d < bestd[rb]) {
-                second[rb] = min(second[rb], bestd[rb]);
+                if (SECOND) second[rb] = min(second[rb], bestd[rb]);
                 bestd[rb] = d;
                 bestcol[rb] = col;
-            } else {
+            } else if (SECOND) {
                 second[rb] = min(second[rb], d);
             }
-            second[rb] = min(second[rb], k2[rb] >> 8);
+            if (SECOND) second[rb] = min(second[rb], k2[rb] >> 8);
         }
         __syncthreads();
     }
@@ -290,7 +297,7 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
             const size_t o = pw.row_off + (size_t)it.chunk * pw.nA_pad + grow;
             rr_d1[o] = bd >= kDistPad ? INT32_MAX : bd + na;
             rr_j1[o] = bc;
-            rr_d2[o] = sc >= kDistPad ? INT32_MAX : sc + na;
+            rr_d2[o] = !SECOND || sc >= kDistPad ? INT32_MAX : sc + na;
         }
     }
 }
@@ -311,12 +318,18 @@ void launch_sift_plan_single(const SiftPair& sp, SiftPair* pair_out, SiftItem* i
 }
 
 void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
-                       int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, hipStream_t s)
+                       int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, bool want_second, hipStream_t s)
 {
-    static DeviceFlags attr_set;   // the attribute is per device
-    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(sift_query_kernel), kLdsStream);
-    hipLaunchKernelGGL(sift_query_kernel, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
-                       pairs, items, rr_d1, rr_j1, rr_d2, -512);
+    static DeviceFlags attr_two, attr_one;   // the attribute is per device and per instantiation
+    if (want_second) {
+        ensure_dynamic_lds(attr_two, reinterpret_cast<const void*>(sift_query_kernel<true>), kLdsStream);
+        hipLaunchKernelGGL(sift_query_kernel<true>, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
+                           pairs, items, rr_d1, rr_j1, rr_d2, -512);
+    } else {
+        ensure_dynamic_lds(attr_one, reinterpret_cast<const void*>(sift_query_kernel<false>), kLdsStream);
+        hipLaunchKernelGGL(sift_query_kernel<false>, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
+                           pairs, items, rr_d1, rr_j1, rr_d2, -512);
+    }
 }
 
 // ---- 1b. query pass, tile-minimum form ---------------------------------------------------

@@ -330,7 +330,8 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
                                    c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), c->stream);
         else
             launch_sift_query(c->d_pairs.as<SiftPair>(), c->d_items.as<SiftItem>(), nitems,
-                              c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), c->stream);
+                              c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(),
+                              rule.num2 > 0 || o.want_knn, c->stream);
         if (c->timing) {
             HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
             c->R().ev_valid = true;
@@ -1587,7 +1588,7 @@ extern "C" int vsm_match_pair_noalloc(vsm_ctx* c, int set0, int set1, const vsm_
     // candidate records and their count by the select pass, the verify item list by its plan kernel), so
     // the contents an earlier call left behind are never read and nothing needs clearing.
     launch_sift_plan_single(sp, d_pair, d_items, c->stream);
-    launch_sift_query(d_pair, d_items, nitems, rr1, rrj, rr2, c->stream);
+    launch_sift_query(d_pair, d_items, nitems, rr1, rrj, rr2, p->ratio_num > 0, c->stream);
     SiftOutputs out{};
     out.slot_i0 = idx0_dev;
     out.slot_i1 = idx1_dev;

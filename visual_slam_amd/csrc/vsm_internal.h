@@ -185,9 +185,10 @@ void launch_sift_transform(const uint8_t* des, int n, int n_pad, int8_t* frag, i
 // one-pair submission planned on the device: *pair_out = sp (row_off = out0_off = out1_off = 0), items =
 // every (strip, chunk) of it in strip-major order
 void launch_sift_plan_single(const SiftPair& sp, SiftPair* pair_out, SiftItem* items, hipStream_t s);
-// query-side pass: per (chunk, query row) best train row, its distance, runner-up distance
+// query-side pass: per (chunk, query row) best train row, its distance, runner-up distance (INT32_MAX
+// throughout without want_second: a cheaper epilogue for callers that never look at it)
 void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
-                       int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, hipStream_t s);
+                       int32_t* rr_d1, int32_t* rr_j1, int32_t* rr_d2, bool want_second, hipStream_t s);
 // Tile-minimum form of the query pass and its follow-ups (ratio-test submissions): per (chunk, query row)
 // the smallest half-distance y1, the 8-row group of a 32-row train tile that holds it (tile * 4 + lane quarter),
 // and the smallest half-distance outside that group; select with optimistic tests (a superset of the final
