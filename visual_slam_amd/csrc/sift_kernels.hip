@@ -857,18 +857,26 @@ void sift_verify_rows_kernel(const SiftPair* __restrict__ pairs, const int32_t* 
     for (int i0 = 0; i0 < pw.nA; i0 += 1024 * R) {
         const int ib = i0 + tid * R;
         unsigned okbits = 0;
+        int nn_keep[R] = {0, 0, 0, 0};
         if (ib < pw.nA) {
             const int4 y = *reinterpret_cast<const int4*>(rr_y1 + pw.row_off + ib);
             const int4 na = *reinterpret_cast<const int4*>(pw.nrmA + ib);
             const int yy[R] = {y.x, y.y, y.z, y.w}, nn[R] = {na.x, na.y, na.z, na.w};
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+            for (int r = 0; r < R; ++r) {
+                nn_keep[r] = nn[r];
                 if (ib + r < pw.nA && yy[r] < kYPad && 2ll * yy[r] + (nn[r] >> 8) <= dmax) okbits |= 1u << r;
+            }
         }
         int slot = block_compact_range(__popc(okbits), wsum, &base_s);
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if ((okbits >> r) & 1u) cand.vrows[pw.out0_off + slot++] = ib + r;
+            if ((okbits >> r) & 1u) {
+                // the packed norm the verify pass streams for this position: the position is the row code
+                cand.vrows[pw.out0_off + slot] = ib + r;
+                cand.vcodes[pw.out0_off + slot] = (nn_keep[r] & ~255) | (slot & 255);
+                ++slot;
+            }
     }
     __syncthreads();
     if (tid == 0) cand.nvrows[blockIdx.x] = base_s;
@@ -949,31 +957,47 @@ void sift_verify_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __re
     // One step of listed rows: every lane fetches the 16-byte pieces of its own row of the wave's two tiles out
     // of whichever tile of image 0 holds it (LDS-DMA takes a global address per lane), and the packed norm of
     // the row at its position of the step, with the position as the row code.
-    auto stage_rows = [&](int buf, int st) {
-        char* dst = smem + buf * kLdsTile + wave * (kLdsTile / kVerifyWaves);
+    // The list entries a step needs (two rows per lane, one packed norm) are fetched a step before the staging that
+    // uses them, so that no staging waits for a load it has just issued.
+    const int32_t* __restrict__ vcodes = cand.vcodes ? cand.vcodes + pw.out0_off : nullptr;
+    int id_row[2] = {0, 0}, id_code = kNormPad;
+    auto fetch_ids = [&](int st) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int pos = st * kStepRows + (wave * 2 + tt) * 32 + lane5;
-            const int row = pos < nv ? vrows[pos] : 0;
-            const int8_t* src = (pos < nv ? pw.fragA + (size_t)(row >> 5) * kTileBytes : cand.zero_tile) + (half * 32 + (row & 31)) * 16;
+            id_row[tt] = pos < nv ? vrows[pos] : -1;
+        }
+        const int pos = st * kStepRows + wave * 64 + lane;
+        id_code = pos < nv ? vcodes[pos] : (kNormPad | (pos & 255));
+    };
+    auto stage_rows = [&](int buf) {
+        char* dst = smem + buf * kLdsTile + wave * (kLdsTile / kVerifyWaves);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int row = id_row[tt];
+            const int8_t* src = (row >= 0 ? pw.fragA + (size_t)(row >> 5) * kTileBytes + (half * 32 + (row & 31)) * 16
+                                          : cand.zero_tile + (half * 32 + lane5) * 16);
 #pragma unroll
             for (int s = 0; s < 4; ++s) dma16(src + s * 1024, dst + (tt * 4 + s) * 1024);
         }
-        const int pos = st * kStepRows + wave * 64 + lane;
-        const int code = pos < nv ? (pw.nrmA[vrows[pos]] & ~255) : kNormPad;
-        reinterpret_cast<int*>(smem + 2 * kLdsTile + buf * kLdsNorm)[wave * 64 + lane] = code | (pos & 255);
+        reinterpret_cast<int*>(smem + 2 * kLdsTile + buf * kLdsNorm)[wave * 64 + lane] = id_code;
     };
     auto stage = [&](int buf, int st) {
-        if (vrows) stage_rows(buf, st);
+        if (vrows) stage_rows(buf);
         else stage_step<kVerifyWaves>(smem, buf, Asrc + (size_t)st * kLdsTile, Nsrc + st * kStepRows, wave);
     };
 
+    if (vrows) fetch_ids(st0);
     stage(0, st0);
+    if (vrows && st0 + 1 < st1) fetch_ids(st0 + 1);
     __syncthreads();
 
     for (int st = st0; st < st1; ++st) {
         const int cur = (st - st0) & 1;
-        if (st + 1 < st1) stage(cur ^ 1, st + 1);
+        if (st + 1 < st1) {
+            stage(cur ^ 1, st + 1);
+            if (vrows && st + 2 < st1) fetch_ids(st + 2);
+        }
         const char* At = smem + cur * kLdsTile + lane * 16;
         const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm);
         int m[kVerifyRB];

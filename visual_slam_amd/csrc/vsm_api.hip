@@ -279,9 +279,9 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     HIPCHK(c, c->d_rr1.ensure(rows * 4));
     HIPCHK(c, c->d_rrj.ensure(rows * 4));
     HIPCHK(c, c->d_rr2.ensure(rows * 4));
-    // vbest (8) + i0, j1, d1, aux (4 each) + rescan list (8) + row list of the verify pass (4) per row, then
+    // vbest (8) + i0, j1, d1, aux (4 each) + rescan list (8) + row list of the verify pass (4 + 4) per row, then
     // per-pair counts, largest accepted distances and row-list lengths, and the rescan counter
-    HIPCHK(c, c->d_cand.ensure(out0 * 36 + sizeof(int32_t) * (3 * std::max(npairs, 1) + 16)));
+    HIPCHK(c, c->d_cand.ensure(out0 * 40 + sizeof(int32_t) * (3 * std::max(npairs, 1) + 16)));
     if (!c->d_zero_tile.p) {
         HIPCHK(c, c->d_zero_tile.ensure(kTileBytes));
         HIPCHK(c, hipMemsetAsync(c->d_zero_tile.p, 0, kTileBytes, c->stream));
@@ -346,13 +346,15 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
         cand.aux = cand.d1 + out0;
         cand.rescan_list = reinterpret_cast<int2*>(cand.aux + out0);
         int32_t* row_list = reinterpret_cast<int32_t*>(cand.rescan_list + out0);
-        cand.count = row_list + out0;
+        int32_t* row_codes = row_list + out0;
+        cand.count = row_codes + out0;
         int32_t* dmax = cand.count + std::max(npairs, 1);
         int32_t* nvrows = dmax + std::max(npairs, 1);
         cand.rescan_count = nvrows + std::max(npairs, 1);
         if (tile_path) {   // the packed path has no bound on the rows that matter: its verify pass streams them all
             cand.dmax = dmax;
             cand.vrows = row_list;
+            cand.vcodes = row_codes;
             cand.nvrows = nvrows;
             cand.zero_tile = c->d_zero_tile.as<int8_t>();
         }

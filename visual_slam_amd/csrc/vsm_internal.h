@@ -86,6 +86,7 @@ struct SiftCandidates {
     // counts them.  NULL in the packed path: the verify pass then streams all of image 0.
     int32_t* dmax;
     int32_t* vrows;
+    int32_t* vcodes;   // per listed row: its squared norm << 8 | (position in the list & 255), the word the verify pass streams
     int32_t* nvrows;
     // one 32-row tile of zero operands (kTileBytes): what the positions past the end of a row list stream, so
     // that their packed keys stay the padding constant (a real row's products would overflow it)
