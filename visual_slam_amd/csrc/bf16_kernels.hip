@@ -593,12 +593,6 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
     const uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
     auto sub_index = [&](int sid) { return ((size_t)(sid >> 1) * pr.nA_pad + i) * 2 + (sid & 1); };
 
-    if (live) {
-        const float4* pa = reinterpret_cast<const float4*>(P.rowsA + (size_t)qrow * DIMP) + sub * Q;
-        float4* dst = reinterpret_cast<float4*>(&s_a[wave][grp][0]) + sub * Q;
-#pragma unroll
-        for (int u = 0; u < Q; ++u) dst[u] = pa[u];
-    }
     const bool l2 = pr.metric == 1;
     const float na = live ? pr.nrmA[qrow] : 0.0f;
     const float margin = coarse_margin(l2, na, *P.maxnormB_sq);
@@ -606,12 +600,13 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
 
     // final coarse runner-up over all splits and both lane halves
     float T1 = -INFINITY, T2 = -INFINITY;
-    int cnt_first = 0;
+    int cnt_first = 0, cnt_any = 0;
     if (live) {
         for (int sid = sub; sid < nsub; sid += 8) {
             const CoarsePart cp = part[sub_index(sid)];
             T2 = fmaxf(fmaxf(T2, cp.t2), fminf(T1, cp.t1));
             T1 = fmaxf(T1, cp.t1);
+            cnt_any |= cp.count;
             if (sid == sub) cnt_first = cp.count;
         }
     }
@@ -620,8 +615,17 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
         const float o1 = __shfl_xor(T1, m), o2 = __shfl_xor(T2, m);
         T2 = fmaxf(fmaxf(T2, o2), fminf(T1, o1));
         T1 = fmaxf(T1, o1);
+        cnt_any |= __shfl_xor(cnt_any, m);
     }
     const float thr = fmaxf((P.top1 ? T1 : T2) - margin, floorc);
+    // the query row is only ever read while a surviving row is scored: a query whose lists are all empty
+    // (a best score under the floor of a thresholded search) leaves it in memory
+    if (cnt_any != 0) {
+        const float4* pa = reinterpret_cast<const float4*>(P.rowsA + (size_t)qrow * DIMP) + sub * Q;
+        float4* dst = reinterpret_cast<float4*>(&s_a[wave][grp][0]) + sub * Q;
+#pragma unroll
+        for (int u = 0; u < Q; ++u) dst[u] = pa[u];
+    }
     __syncthreads();   // query rows staged
 
     Best2 best;   // the same in every lane of the group
