@@ -505,3 +505,45 @@ def test_large_submission_searches_the_candidates_only(matcher, f32_mode):
         matcher.set_f32_reverse(vsm.F32_REVERSE_AUTO)
         for sid in ids:
             matcher.release(sid)
+
+
+@pytest.mark.parametrize("dim", [64, 128, 256])
+@pytest.mark.parametrize("ncand", [1, 31, 33, 127, 129, 700])
+def test_contested_columns_with_the_reverse_search_over_the_candidates_rows(matcher, f32_mode, dim, ncand):
+    """Dot product + score threshold + mutual, candidates-only reverse searches: the reverse search of a pair
+    looks at the candidates' rows of image 0 only.  `ncand` rows of image 0 have a partner above the threshold
+    (list lengths either side of the 32-row tiles and of the 16 KiB steps at every dimension), and many of them
+    contest the same train row: groups of query rows are noisy copies of ONE train row, so every column of a group
+    has several candidates of which only the best (lowest row on exact ties: some copies are exact duplicates)
+    survives.  Lists equal the both-directions form and the oracle's."""
+    rng = np.random.default_rng(1000 * dim + ncand)
+    n0, n1 = 900, 777
+    a = synth.unit_f32(n0, dim, rng)
+    b = synth.unit_f32(n1, dim, rng)
+    rows = rng.choice(n0, ncand, replace=False)
+    cols = rng.choice(n1, max(1, ncand // 3), replace=False)
+    for k, r in enumerate(rows):
+        v = b[cols[k % len(cols)]] + (0.0 if k % 5 == 0 else 0.04) * rng.standard_normal(dim).astype(np.float32)
+        a[r] = v / np.linalg.norm(v)
+    a = np.ascontiguousarray(a, np.float32)
+    s0, s1 = matcher.upload_f32(a), matcher.upload_f32(b)
+    pr = np.asarray([[s0, s1], [s1, s0], [s0, s0]], np.int32)
+    try:
+        lists = {}
+        for mode in (vsm.F32_REVERSE_CANDIDATES, vsm.F32_REVERSE_ALL):
+            matcher.set_f32_reverse(mode)
+            lists[mode] = matcher.match_pairs(pr, ratio=None, mutual=True, metric=vsm.METRIC_DOT, min_score=0.75)
+        for x, y in zip(lists[vsm.F32_REVERSE_CANDIDATES], lists[vsm.F32_REVERSE_ALL]):
+            np.testing.assert_array_equal(x, y)
+        off, i0, i1 = lists[vsm.F32_REVERSE_CANDIDATES]
+        for k, (x, y) in enumerate([(a, b), (b, a), (a, a)]):
+            o0, _, _, _ = orc.match_dense_f32(x, y, orc.METRIC_DOT, orc.params(None, True, min_score=0.75))
+            sel = np.nonzero(o0 >= 0)[0]
+            np.testing.assert_array_equal(i0[off[k]:off[k + 1]], sel)
+            np.testing.assert_array_equal(i1[off[k]:off[k + 1]], o0[sel])
+        assert 0 < off[1] <= len(cols)          # one survivor per contested column at most
+        assert off[3] - off[2] >= n0 - ncand    # a set against itself: every row whose only duplicate is itself
+    finally:
+        matcher.set_f32_reverse(vsm.F32_REVERSE_AUTO)
+        matcher.release(s0)
+        matcher.release(s1)

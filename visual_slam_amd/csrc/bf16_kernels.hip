@@ -24,6 +24,11 @@
 //    Queries whose best score is not above the floor come out with no row at all (-1).
 // And a query list (qlist / qcount) restricts a search to some rows of A, chosen on the device by an earlier
 // kernel: the mutual check of a pair only asks about the train rows that some query row has chosen.
+// A database list (dblist / dbcount) restricts it to some rows of B the same way: under a pure threshold rule a
+// row that could come before a candidate in its column is a candidate itself (its own best score is at least
+// its score in that column, which is at least the candidate's), so the reverse searches of a mutual check only
+// look at the candidates' rows.  Each lane of a staging wave fetches the 16-byte pieces of ITS row out of
+// whichever tile holds it; positions past the end of the list take the start value of a padding row (-inf).
 #include "f32_kernels.h"
 
 #include <math.h>
@@ -165,7 +170,7 @@ __device__ __forceinline__ int find_problem(int nprobs, int L, GetFirst first)
     return lo;
 }
 
-template <int DIMP, bool TOP1>
+template <int DIMP, bool TOP1, bool DBL>
 __global__ __launch_bounds__(kCoarseWaves * 64, 2)
 void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
                         CoarsePart* __restrict__ part_all, uint2* __restrict__ lists_all, int* __restrict__ overflow)
@@ -241,16 +246,53 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
         cnt[rb] = 0;
     }
 
-    const int ntiles = pr.nB_pad >> 5;
-    const int t0 = split * tiles_per_split;                       // multiples of 8 tiles, as is ntiles
+    const int32_t* __restrict__ dblist = P.dblist;
+    const int ndb = DBL ? *P.dbcount : 0;
+    // whole steps either way: multiples of 8 tiles without a list, the listed rows rounded up to a step with one
+    const int ntiles = DBL ? (ndb + STEP_ROWS - 1) / STEP_ROWS * STEP_TILES : pr.nB_pad >> 5;
+    const int t0 = split * tiles_per_split;
     const int t1e = min(t0 + tiles_per_split, ntiles);
-    const int nsteps = (t1e - t0) / STEP_TILES;
+    const int nsteps = max(t1e - t0, 0) / STEP_TILES;
+
+    // database list: the rows at this lane's positions (lane & 31 of every tile) of the step staged next,
+    // fetched a step ahead of the staging that uses them; -1 past the end of the list
+    int rid[STEP_TILES];
+    auto fetch_ids = [&](int st) {
+        if (!DBL) return;
+#pragma unroll
+        for (int tt = 0; tt < STEP_TILES; ++tt) {
+            const int pos = (t0 + st * STEP_TILES + tt) * 32 + lane5;
+            rid[tt] = pos < ndb ? dblist[pos] : -1;
+        }
+    };
+    auto rid_of = [&](int tt) {
+        int r = rid[0];
+#pragma unroll
+        for (int k = 1; k < STEP_TILES; ++k) r = tt == k ? rid[k] : r;
+        return r;
+    };
 
     auto stage = [&](auto BUF, int st) {
         constexpr int buf = decltype(BUF)::value;
         const int tile = t0 + st * STEP_TILES;
-        const char* src = reinterpret_cast<const char*>(bfB) + (size_t)tile * TILE_BYTES + lane * 16;
         char* dst = smem + buf * kCoarseStepBytes;
+        if (DBL) {
+#pragma unroll
+            for (int p = 0; p < kCoarseStepBytes / 1024 / kCoarseWaves; ++p) {
+                const int piece = wave + p * kCoarseWaves;   // 1 KiB = (tile of the step, k-step): 64 lanes = (half, row)
+                const int row = max(rid_of(piece / S), 0);   // padding positions stage some real row; their start value is -inf
+                const char* src = reinterpret_cast<const char*>(bfB) + ((size_t)(row >> 5) * S + (piece % S)) * 1024 +
+                                  (half * 32 + (row & 31)) * 16;
+                __builtin_amdgcn_global_load_lds((const VSM_GLB void*)src, (VSM_LDS void*)(dst + piece * 1024), 16, 0, 0);
+            }
+            if (wave * 64 < STEP_ROWS) {
+                const int r = rid_of(min(wave * 2 + half, STEP_TILES - 1));
+                __builtin_amdgcn_global_load_lds((const VSM_GLB void*)(initB + (r >= 0 ? r : pr.nB_pad)),
+                                                 (VSM_LDS void*)((buf ? s_init1 : s_init0) + wave * 64), 4, 0, 0);
+            }
+            return;
+        }
+        const char* src = reinterpret_cast<const char*>(bfB) + (size_t)tile * TILE_BYTES + lane * 16;
 #pragma unroll
         for (int p = 0; p < kCoarseStepBytes / 1024 / kCoarseWaves; ++p) {
             const int piece = wave + p * kCoarseWaves;
@@ -334,14 +376,18 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
 
     using Buf0 = std::integral_constant<int, 0>;
     using Buf1 = std::integral_constant<int, 1>;
+    fetch_ids(0);
     if (nsteps > 0) stage(Buf0{}, 0);
+    fetch_ids(1);
     __syncthreads();
     for (int st = 0; st < nsteps; st += 2) {
         if (st + 1 < nsteps) stage(Buf1{}, st + 1);
+        fetch_ids(st + 2);
         compute(Buf0{}, st);
         __syncthreads();
         if (st + 1 < nsteps) {
             if (st + 2 < nsteps) stage(Buf0{}, st + 2);
+            fetch_ids(st + 3);
             compute(Buf1{}, st + 1);
             __syncthreads();
         }
@@ -432,6 +478,9 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
     const float floorc = l2 ? -INFINITY : P.key_floor - 0.5f * margin;
     const int nsub = nsplits * 2;
     auto sub_index = [&](int sid) { return ((size_t)(sid >> 1) * pr.nA_pad + i) * 2 + (sid & 1); };
+    // with a database list the entries name positions in it
+    const int32_t* __restrict__ dblist = P.dblist;
+    const int nrows_b = dblist ? *P.dbcount : pr.nB;
 
     // final coarse runner-up over all splits and both lane halves
     float T1 = -INFINITY, T2 = -INFINITY;
@@ -520,8 +569,9 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
             unsigned bits = ex & 0xffffu;
             while (__ballot(bits != 0)) {
                 const int reg = bits ? __ffs(bits) - 1 : 0;
-                const int row = entry_row(ex, reg, sid & 1, first_tile);
-                const bool keep = bits != 0 && row < pr.nB;
+                int row = entry_row(ex, reg, sid & 1, first_tile);
+                const bool keep = bits != 0 && row < nrows_b;
+                if (dblist && keep) row = dblist[row];
                 bits &= bits - 1;
                 const unsigned long long mask = __ballot(keep);
                 const int n = __popcll(mask);
@@ -592,6 +642,9 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
     const CoarsePart* __restrict__ part = part_all + P.part_off;
     const uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
     auto sub_index = [&](int sid) { return ((size_t)(sid >> 1) * pr.nA_pad + i) * 2 + (sid & 1); };
+    // with a database list the entries name positions in it
+    const int32_t* __restrict__ dblist = P.dblist;
+    const int nrows_b = dblist ? *P.dbcount : pr.nB;
 
     const bool l2 = pr.metric == 1;
     const float na = live ? pr.nrmA[qrow] : 0.0f;
@@ -720,7 +773,7 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
                             const int reg = sub + 8 * h;
                             if ((bits >> reg) & 1u) {
                                 const int r = entry_row(x, reg, sid & 1, first_tile);
-                                queue[nq + __popc(bits & ((1u << reg) - 1u))] = r < pr.nB ? r : -1;
+                                queue[nq + __popc(bits & ((1u << reg) - 1u))] = r < nrows_b ? (dblist ? dblist[r] : r) : -1;
                             }
                         }
                         nq += __popc(bits);
@@ -779,34 +832,41 @@ size_t coarse_scratch_bytes(const CoarseTotals& t)
     return part_bytes(t.sublists) + (size_t)t.sublists * kCoarseCap * sizeof(uint2) + 256;
 }
 
-template <int DIMP, bool TOP1>
+template <int DIMP, bool TOP1, bool DBL>
 static void launch_coarse_t(const CoarseProblem* d_probs, int nprobs, int blocks, CoarsePart* part, uint2* lists,
                             int* overflow, hipStream_t s)
 {
     const int lds = 2 * kCoarseStepBytes;
     static DeviceFlags attr_set;   // the attribute is per device (and per instantiation: one flag set each)
-    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(bf16_coarse_kernel<DIMP, TOP1>), lds);
-    hipLaunchKernelGGL((bf16_coarse_kernel<DIMP, TOP1>), dim3(blocks), dim3(kCoarseWaves * 64), lds, s,
+    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(bf16_coarse_kernel<DIMP, TOP1, DBL>), lds);
+    hipLaunchKernelGGL((bf16_coarse_kernel<DIMP, TOP1, DBL>), dim3(blocks), dim3(kCoarseWaves * 64), lds, s,
                        d_probs, nprobs, part, lists, overflow);
+}
+
+template <int DIMP>
+static void launch_coarse_d(const CoarseProblem* d_probs, int nprobs, int blocks, CoarsePart* part, uint2* lists,
+                            int* overflow, hipStream_t s, bool top1, bool db_lists)
+{
+    if (db_lists) {
+        if (top1) launch_coarse_t<DIMP, true, true>(d_probs, nprobs, blocks, part, lists, overflow, s);
+        else launch_coarse_t<DIMP, false, true>(d_probs, nprobs, blocks, part, lists, overflow, s);
+    } else {
+        if (top1) launch_coarse_t<DIMP, true, false>(d_probs, nprobs, blocks, part, lists, overflow, s);
+        else launch_coarse_t<DIMP, false, false>(d_probs, nprobs, blocks, part, lists, overflow, s);
+    }
 }
 
 void launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
                        int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow,
-                       hipStream_t s, bool top1)
+                       hipStream_t s, bool top1, bool db_lists)
 {
     if (nprobs <= 0 || t.coarse_blocks <= 0) return;
     CoarsePart* part = static_cast<CoarsePart*>(scratch);
     uint2* lists = reinterpret_cast<uint2*>(static_cast<char*>(scratch) + part_bytes(t.sublists));
     const int dimp = f32_dimp(dim);
-    if (top1) {
-        if (dimp == 64) launch_coarse_t<64, true>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
-        else if (dimp == 128) launch_coarse_t<128, true>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
-        else launch_coarse_t<256, true>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
-    } else {
-        if (dimp == 64) launch_coarse_t<64, false>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
-        else if (dimp == 128) launch_coarse_t<128, false>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
-        else launch_coarse_t<256, false>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s);
-    }
+    if (dimp == 64) launch_coarse_d<64>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s, top1, db_lists);
+    else if (dimp == 128) launch_coarse_d<128>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s, top1, db_lists);
+    else launch_coarse_d<256>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s, top1, db_lists);
     if (t.rerank_blocks <= 0) return;
     // many queries with few sublists each: eight queries per wave; few queries with many sublists
     // (a sliced database): one wave per query

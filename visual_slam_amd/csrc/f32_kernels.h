@@ -99,6 +99,10 @@ struct CoarseProblem {
     // are indexed by slot, and pr.nA / pr.nA_pad are then the capacity of the list, not A's row count.
     const int32_t* qlist;
     const int32_t* qcount;
+    // Optional database list: position d (< *dbcount) of the search is row dblist[d] of B, ascending; tiles, list
+    // entries and ties go by position, results name rows.  pr.nB / pr.nB_pad stay B's own (the capacity).
+    const int32_t* dblist;
+    const int32_t* dbcount;
 };
 
 struct CoarseTotals {
@@ -113,12 +117,12 @@ struct CoarseTotals {
 // out_rows0: first output row (a second group of problems of the same submission continues after the first).
 CoarseTotals plan_coarse(CoarseProblem* probs, int n, int target_wgs, int64_t out_rows0 = 0);
 size_t coarse_scratch_bytes(const CoarseTotals& t);
-// All problems must share f32_dimp(dim) and top1.  Outputs as launch_f32_knn's query side at out_off, bit for
+// All problems must share f32_dimp(dim), top1 and whether they carry a database list.  Outputs as launch_f32_knn's query side at out_off, bit for
 // bit, PROVIDED *overflow (device int, cleared by the caller) reads 0 afterwards; a set flag means a
 // survivor list was too short and the results are void.
 void launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
                        int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow,
-                       hipStream_t s, bool top1 = false);
+                       hipStream_t s, bool top1 = false, bool db_lists = false);
 
 // L2 searches only (problems of the other metric are skipped): orders each query's two best rows by the
 // difference-form squared distance and stores those distances in k1 / k2.  Problems come from device memory

@@ -996,6 +996,12 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     const bool selective = dot ? rule.min_score > -INFINITY : (rule.ratio_num > 0 || rule.max_dist >= 0.0f);
     const bool two_phase = nrev > 0 && (c->f32_reverse == VSM_F32_REVERSE_CANDIDATES ||
                                         (c->f32_reverse == VSM_F32_REVERSE_AUTO && selective && pl.work >= (double)(1 << 28)));
+    // Dot ranking, candidates only: the accept test is a threshold on the very score the searches rank by, so a row
+    // that scores at least what a candidate scores in the candidate's column passes it with its own best score
+    // and is a candidate itself; the reverse searches then look at the candidates' rows only (their list, as it
+    // lies in the output slots of image 0, is ascending).  Not for L2: its results are re-ordered by the
+    // difference form afterwards, and the two orders need not agree on rows that were left out.
+    const bool db_lists = two_phase && dot;
     c->R().ev_valid = false;
     c->timing_slot = c->rs;
     c->last_f32_reverse = nrev == 0 ? -1 : two_phase ? VSM_F32_REVERSE_CANDIDATES : VSM_F32_REVERSE_ALL;
@@ -1030,6 +1036,10 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
             q.pr.nA_pad = pl.pairs[p].nA_pad;
             q.qlist = c->d_slot1.as<int32_t>() + pl.pairs[p].out0_off;
             q.qcount = c->d_counts.as<int32_t>() + p;
+            if (db_lists) {
+                q.dblist = c->d_slot0.as<int32_t>() + pl.pairs[p].out0_off;
+                q.dbcount = q.qcount;
+            }
         }
     // geometry and offsets: one group when both directions go in one launch, else two
     CoarseTotals t1, t2;
@@ -1079,9 +1089,9 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     int32_t* j2 = c->d_rrj.as<int32_t>();
     float* k1 = c->d_knn1.as<float>();
     float* k2 = c->d_knn2.as<float>();
-    auto search = [&](const CoarseProblem* dp, const CoarseProblem* hp, int n, const CoarseTotals& t) {
+    auto search = [&](const CoarseProblem* dp, const CoarseProblem* hp, int n, const CoarseTotals& t, bool lists) {
         if (n <= 0) return;
-        launch_bf16_batch(dp, n, pl.dim, t, j1, j2, k1, k2, c->d_coarse.p, c->flag_dev, c->stream, dot);
+        launch_bf16_batch(dp, n, pl.dim, t, j1, j2, k1, k2, c->d_coarse.p, c->flag_dev, c->stream, dot, lists);
         if (!dot) {
             int max_rows = 0;
             for (int i = 0; i < n; ++i) max_rows = std::max(max_rows, hp[i].pr.nA);
@@ -1096,17 +1106,17 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     out.dense0 = o.want_dense ? c->d_dense0.as<int32_t>() : nullptr;
     out.dense1 = o.want_dense ? c->d_dense1.as<int32_t>() : nullptr;
     if (two_phase) {
-        search(d_probs, pl.probs.data(), nfwd, t1);
+        search(d_probs, pl.probs.data(), nfwd, t1, false);
         F32Rule first = rule;
         first.mutual = 0;
         SiftOutputs cand = out;
         cand.dense0 = nullptr;
         cand.dense1 = nullptr;
         launch_f32_accept(d_pairs, d_refs, npairs, first, j1, k1, k2, cand, c->stream);
-        search(d_probs + nfwd, pl.probs.data() + nfwd, nrev, t2);
+        search(d_probs + nfwd, pl.probs.data() + nfwd, nrev, t2, db_lists);
         launch_f32_confirm(d_pairs, d_refs, npairs, j1, out, c->stream);
     } else {
-        search(d_probs, pl.probs.data(), nprobs, t1);
+        search(d_probs, pl.probs.data(), nprobs, t1, false);
         launch_f32_accept(d_pairs, d_refs, npairs, rule, j1, k1, k2, out, c->stream);
     }
     if (c->timing) {
