@@ -94,7 +94,9 @@ int vsm_set_f32_mode(vsm_ctx* ctx, int mode);
 int vsm_last_f32_path(const vsm_ctx* ctx);
 /* Mutual check of float pair submissions (fast mode).  The reverse searches of a submission can run after the
  * forward ones, over only the train rows that candidates which passed the score / distance / ratio tests name
- * (VSM_F32_REVERSE_CANDIDATES), or together with them over every train row (VSM_F32_REVERSE_ALL).  Same lists
+ * (VSM_F32_REVERSE_CANDIDATES; on the dot-product ranking they also look at the candidates' own rows of the
+ * first image only, since no other row can outscore a candidate in its column), or together with them over
+ * every train row (VSM_F32_REVERSE_ALL).  Same lists
  * either way.  VSM_F32_REVERSE_AUTO (default) takes the first for large submissions whose rule has such a
  * test and the second otherwise (one launch less per stage matters for a single small pair). */
 enum { VSM_F32_REVERSE_AUTO = 0, VSM_F32_REVERSE_CANDIDATES = 1, VSM_F32_REVERSE_ALL = 2 };
