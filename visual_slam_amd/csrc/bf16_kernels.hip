@@ -612,7 +612,7 @@ constexpr int kGroupWaves = 4;
 constexpr int kGroupQueries = kGroupWaves * 8;   // queries per workgroup
 constexpr int kGroupQueue = 32;                  // surviving rows a group collects before the wave scores them
 
-template <int DIMP>
+template <int DIMP, bool CHAIN8>
 __global__ __launch_bounds__(kGroupWaves * 64)
 void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
                               const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
@@ -623,8 +623,8 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
     constexpr int NBLK = DIMP / 32;   // 32-column blocks of a row
     constexpr int AST = DIMP + 4;     // LDS stride of a query row: the eight rows of a wave start in different banks
     __shared__ int s_queue[kGroupWaves][8][kGroupQueue];
-    __shared__ float s_score[kGroupWaves][8][kGroupQueue];
-    __shared__ __attribute__((aligned(16))) float s_a[kGroupWaves][8][AST];
+    __shared__ float s_score[CHAIN8 ? 1 : kGroupWaves][8][kGroupQueue];
+    __shared__ __attribute__((aligned(16))) float s_a[CHAIN8 ? 1 : kGroupWaves][8][CHAIN8 ? 4 : AST];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int sub = lane & 7, grp = lane >> 3, gbase = lane & ~7;
@@ -637,7 +637,7 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
     const bool live = i < nslots;
     const int qrow = live ? (qlist ? qlist[i] : i) : 0;
     volatile int* queue = s_queue[wave][grp];
-    volatile float* score = s_score[wave][grp];
+    volatile float* score = s_score[CHAIN8 ? 0 : wave][grp];
     const int nsub = P.nsplits * 2;
     const CoarsePart* __restrict__ part = part_all + P.part_off;
     const uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
@@ -673,20 +673,63 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
     const float thr = fmaxf((P.top1 ? T1 : T2) - margin, floorc);
     // the query row is only ever read while a surviving row is scored: a query whose lists are all empty
     // (a best score under the floor of a thresholded search) leaves it in memory
+    float4 areg[CHAIN8 ? Q : 1];   // CHAIN8: columns [sub * DIMP / 8, (sub + 1) * DIMP / 8) of the group's query row
     if (cnt_any != 0) {
         const float4* pa = reinterpret_cast<const float4*>(P.rowsA + (size_t)qrow * DIMP) + sub * Q;
-        float4* dst = reinterpret_cast<float4*>(&s_a[wave][grp][0]) + sub * Q;
+        if (CHAIN8) {
 #pragma unroll
-        for (int u = 0; u < Q; ++u) dst[u] = pa[u];
+            for (int u = 0; u < Q; ++u) areg[u] = pa[u];
+        } else {
+            float4* dst = reinterpret_cast<float4*>(&s_a[wave][grp][0]) + sub * Q;
+#pragma unroll
+            for (int u = 0; u < Q; ++u) dst[u] = pa[u];
+        }
     }
-    __syncthreads();   // query rows staged
+    if (!CHAIN8) __syncthreads();   // query rows staged
 
     Best2 best;   // the same in every lane of the group
     best.s1 = -INFINITY; best.s2 = -INFINITY; best.r1 = -1; best.r2 = -1;
     int nq = 0;   // rows in this group's queue (the same in every lane of the group)
 
     // whole wave: score every queued (query, row) pair, one per lane, then each group folds its own
+    // CHAIN8: every group scores the rows of its own queue, one row per round.  Lane `sub` holds the same columns
+    // of the row as of the query (the whole row in one round trip to memory) and the k-ascending chain runs
+    // through the group's lanes in order, handed on by a shuffle: few rows per query (top-1 searches, most of
+    // whose queries have one survivor or none) cost one round trip each instead of one per 32 columns.
     auto score_all = [&]() {
+        if constexpr (CHAIN8) {
+            int rounds = nq;
+#pragma unroll
+            for (int m = 8; m < 64; m <<= 1) rounds = max(rounds, __shfl_xor(rounds, m));
+            for (int q = 0; q < rounds; ++q) {
+                const int row = q < nq ? queue[q] : -1;
+                const bool act = row >= 0;
+                const float4* pb = reinterpret_cast<const float4*>(P.rowsB + (size_t)(act ? row : 0) * DIMP) + sub * Q;
+                float4 b[Q];
+#pragma unroll
+                for (int u = 0; u < Q; ++u) b[u] = pb[u];
+                const float nbr = l2 ? pr.nrmB[act ? row : 0] : 0.0f;
+                float d = 0.0f;
+#pragma unroll
+                for (int stage = 0; stage < 8; ++stage) {
+                    if (sub == stage) {
+#pragma unroll
+                        for (int u = 0; u < Q; ++u) {
+                            d = fmaf(b[u].x, areg[u].x, d);
+                            d = fmaf(b[u].y, areg[u].y, d);
+                            d = fmaf(b[u].z, areg[u].z, d);
+                            d = fmaf(b[u].w, areg[u].w, d);
+                        }
+                    }
+                    const float handed = __shfl(d, gbase + stage);
+                    if (sub == stage + 1) d = handed;
+                    if (stage == 7) d = handed;   // the finished chain, in every lane of the group
+                }
+                const float sc = l2 ? fmaf(2.0f, d, -nbr) : d;
+                if (act && sc > -INFINITY) best2_insert(best, sc, row);
+            }
+            nq = 0;
+        } else {
         int off[9];
         off[0] = 0;
 #pragma unroll
@@ -738,6 +781,7 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
             if (sc > -INFINITY) best2_insert(best, sc, queue[q]);
         }
         nq = 0;
+        }
     };
 
     for (int sid = 0; sid < nsub; ++sid) {
@@ -874,9 +918,16 @@ void launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const 
     if (grouped) {
         const int per = kGroupQueries / kRerankWaves;
         const dim3 grid((t.rerank_blocks + per - 1) / per, nprobs), block(kGroupWaves * 64);
-        if (dimp == 64) hipLaunchKernelGGL(bf16_rerank_group_kernel<64>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
-        else if (dimp == 128) hipLaunchKernelGGL(bf16_rerank_group_kernel<128>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
-        else hipLaunchKernelGGL(bf16_rerank_group_kernel<256>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+        // top-1 searches leave one or two rows per query: the eight-lane chain; else a (query, row) pair per lane
+        if (top1) {
+            if (dimp == 64) hipLaunchKernelGGL((bf16_rerank_group_kernel<64, true>), grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+            else if (dimp == 128) hipLaunchKernelGGL((bf16_rerank_group_kernel<128, true>), grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+            else hipLaunchKernelGGL((bf16_rerank_group_kernel<256, true>), grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+        } else {
+            if (dimp == 64) hipLaunchKernelGGL((bf16_rerank_group_kernel<64, false>), grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+            else if (dimp == 128) hipLaunchKernelGGL((bf16_rerank_group_kernel<128, false>), grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+            else hipLaunchKernelGGL((bf16_rerank_group_kernel<256, false>), grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+        }
     } else {
         const dim3 grid(t.rerank_blocks, nprobs), block(kRerankWaves * 64);
         if (dimp == 64) hipLaunchKernelGGL(bf16_rerank_kernel<64>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
