@@ -17,6 +17,9 @@ def main():
     ap.add_argument("--features", type=int, default=4096)
     ap.add_argument("--pairs", type=int, default=256)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--metric", choices=["dot", "l2"], default="dot")
+    ap.add_argument("--ratio", type=float, default=0.0, help="Lowe ratio (L2 only); 0: none")
+    ap.add_argument("--min-score", type=float, default=0.5, help="score threshold of the dot ranking")
     args = ap.parse_args()
     rng = np.random.default_rng(3)
     n = args.features
@@ -33,7 +36,10 @@ def main():
     pr = np.asarray([[ids[a], ids[b]] for a, b in allp], np.int32)
     m.set_timing(True)
     for _ in range(args.reps):
-        tot = m.match_pairs_device(pr, ratio=None, mutual=True, metric=vsm.METRIC_DOT, min_score=0.5)
+        if args.metric == "dot":
+            tot = m.match_pairs_device(pr, ratio=None, mutual=True, metric=vsm.METRIC_DOT, min_score=args.min_score)
+        else:
+            tot = m.match_pairs_device(pr, ratio=(args.ratio or None), mutual=True, metric=vsm.METRIC_L2)
         m.fetch_matches(len(pr), tot)
     print("pairs %d matches %d kernels %.3f ms" % (len(pr), tot, m.last_kernel_ms()))
     m.close()

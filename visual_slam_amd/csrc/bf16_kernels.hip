@@ -604,27 +604,24 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
 
 // The same re-rank for submissions of many small problems (few sublists per query, millions of
 // queries): eight queries per wave.  A group of eight lanes reads the coarse results and the list
-// entries of one query and queues the rows that survive the final threshold; the wave then scores all
-// queued (query, row) pairs at once, one pair per lane: the lane runs the whole k-ascending chain, the
-// query row read from LDS (lanes of one query read the same address), its own database row straight
-// from memory.  Results are bit-identical to bf16_rerank_kernel.
+// entries of one query and queues the rows that survive the final threshold; every group then scores the
+// rows of its own queue, one row per round: lane `sub` holds the same DIMP / 8 columns of the row as of the
+// query (registers; the whole row in one round trip to memory) and the k-ascending chain runs through the
+// group's lanes in order, handed on by a shuffle.  A query's row is only fetched when one of its lists holds
+// an entry (thresholded searches: most queries have none).  Results are bit-identical to bf16_rerank_kernel.
 constexpr int kGroupWaves = 4;
 constexpr int kGroupQueries = kGroupWaves * 8;   // queries per workgroup
-constexpr int kGroupQueue = 32;                  // surviving rows a group collects before the wave scores them
+constexpr int kGroupQueue = 32;                  // surviving rows a group collects before they are scored
 
-template <int DIMP, bool CHAIN8>
+template <int DIMP>
 __global__ __launch_bounds__(kGroupWaves * 64)
 void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
                               const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
                               int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
                               float* __restrict__ k1_all, float* __restrict__ k2_all)
 {
-    constexpr int Q = DIMP / 32;      // float4 pieces of a query row per lane of its group
-    constexpr int NBLK = DIMP / 32;   // 32-column blocks of a row
-    constexpr int AST = DIMP + 4;     // LDS stride of a query row: the eight rows of a wave start in different banks
+    constexpr int Q = DIMP / 32;      // float4 pieces of a row per lane of a group
     __shared__ int s_queue[kGroupWaves][8][kGroupQueue];
-    __shared__ float s_score[CHAIN8 ? 1 : kGroupWaves][8][kGroupQueue];
-    __shared__ __attribute__((aligned(16))) float s_a[CHAIN8 ? 1 : kGroupWaves][8][CHAIN8 ? 4 : AST];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int sub = lane & 7, grp = lane >> 3, gbase = lane & ~7;
@@ -637,7 +634,6 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
     const bool live = i < nslots;
     const int qrow = live ? (qlist ? qlist[i] : i) : 0;
     volatile int* queue = s_queue[wave][grp];
-    volatile float* score = s_score[CHAIN8 ? 0 : wave][grp];
     const int nsub = P.nsplits * 2;
     const CoarsePart* __restrict__ part = part_all + P.part_off;
     const uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
@@ -673,115 +669,52 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
     const float thr = fmaxf((P.top1 ? T1 : T2) - margin, floorc);
     // the query row is only ever read while a surviving row is scored: a query whose lists are all empty
     // (a best score under the floor of a thresholded search) leaves it in memory
-    float4 areg[CHAIN8 ? Q : 1];   // CHAIN8: columns [sub * DIMP / 8, (sub + 1) * DIMP / 8) of the group's query row
+    float4 areg[Q];   // columns [sub * DIMP / 8, (sub + 1) * DIMP / 8) of the group's query row
+#pragma unroll
+    for (int u = 0; u < Q; ++u) areg[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (cnt_any != 0) {
         const float4* pa = reinterpret_cast<const float4*>(P.rowsA + (size_t)qrow * DIMP) + sub * Q;
-        if (CHAIN8) {
 #pragma unroll
-            for (int u = 0; u < Q; ++u) areg[u] = pa[u];
-        } else {
-            float4* dst = reinterpret_cast<float4*>(&s_a[wave][grp][0]) + sub * Q;
-#pragma unroll
-            for (int u = 0; u < Q; ++u) dst[u] = pa[u];
-        }
+        for (int u = 0; u < Q; ++u) areg[u] = pa[u];
     }
-    if (!CHAIN8) __syncthreads();   // query rows staged
 
     Best2 best;   // the same in every lane of the group
     best.s1 = -INFINITY; best.s2 = -INFINITY; best.r1 = -1; best.r2 = -1;
     int nq = 0;   // rows in this group's queue (the same in every lane of the group)
 
-    // whole wave: score every queued (query, row) pair, one per lane, then each group folds its own
-    // CHAIN8: every group scores the rows of its own queue, one row per round.  Lane `sub` holds the same columns
-    // of the row as of the query (the whole row in one round trip to memory) and the k-ascending chain runs
-    // through the group's lanes in order, handed on by a shuffle: few rows per query (top-1 searches, most of
-    // whose queries have one survivor or none) cost one round trip each instead of one per 32 columns.
+    // whole wave: every group scores the rows of its own queue, as many rounds as the longest queue has rows
     auto score_all = [&]() {
-        if constexpr (CHAIN8) {
-            int rounds = nq;
+        int rounds = nq;
 #pragma unroll
-            for (int m = 8; m < 64; m <<= 1) rounds = max(rounds, __shfl_xor(rounds, m));
-            for (int q = 0; q < rounds; ++q) {
-                const int row = q < nq ? queue[q] : -1;
-                const bool act = row >= 0;
-                const float4* pb = reinterpret_cast<const float4*>(P.rowsB + (size_t)(act ? row : 0) * DIMP) + sub * Q;
-                float4 b[Q];
+        for (int m = 8; m < 64; m <<= 1) rounds = max(rounds, __shfl_xor(rounds, m));
+        for (int q = 0; q < rounds; ++q) {
+            const int row = q < nq ? queue[q] : -1;   // -1: a padding row of the last tile, or no row this round
+            const bool act = row >= 0;
+            const float4* pb = reinterpret_cast<const float4*>(P.rowsB + (size_t)(act ? row : 0) * DIMP) + sub * Q;
+            float4 b[Q];
 #pragma unroll
-                for (int u = 0; u < Q; ++u) b[u] = pb[u];
-                const float nbr = l2 ? pr.nrmB[act ? row : 0] : 0.0f;
-                float d = 0.0f;
+            for (int u = 0; u < Q; ++u) b[u] = pb[u];
+            const float nbr = l2 ? pr.nrmB[act ? row : 0] : 0.0f;
+            float d = 0.0f;
 #pragma unroll
-                for (int stage = 0; stage < 8; ++stage) {
-                    if (sub == stage) {
+            for (int stage = 0; stage < 8; ++stage) {
+                if (sub == stage) {
 #pragma unroll
-                        for (int u = 0; u < Q; ++u) {
-                            d = fmaf(b[u].x, areg[u].x, d);
-                            d = fmaf(b[u].y, areg[u].y, d);
-                            d = fmaf(b[u].z, areg[u].z, d);
-                            d = fmaf(b[u].w, areg[u].w, d);
-                        }
+                    for (int u = 0; u < Q; ++u) {
+                        d = fmaf(b[u].x, areg[u].x, d);
+                        d = fmaf(b[u].y, areg[u].y, d);
+                        d = fmaf(b[u].z, areg[u].z, d);
+                        d = fmaf(b[u].w, areg[u].w, d);
                     }
-                    const float handed = __shfl(d, gbase + stage);
-                    if (sub == stage + 1) d = handed;
-                    if (stage == 7) d = handed;   // the finished chain, in every lane of the group
                 }
-                const float sc = l2 ? fmaf(2.0f, d, -nbr) : d;
-                if (act && sc > -INFINITY) best2_insert(best, sc, row);
+                const float handed = __shfl(d, gbase + stage);
+                if (sub == stage + 1) d = handed;
+                if (stage == 7) d = handed;   // the finished chain, in every lane of the group
             }
-            nq = 0;
-        } else {
-        int off[9];
-        off[0] = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) off[j + 1] = off[j] + __shfl(nq, j * 8);
-        const int total = off[8];
-        for (int t0 = 0; t0 < total; t0 += 64) {
-            const int t = t0 + lane;
-            int g = 0;
-#pragma unroll
-            for (int j = 1; j < 8; ++j) g += off[j] <= t ? 1 : 0;
-            const bool valid = t < total;
-            int og = 0;   // off[g] without indexing registers by a lane-varying value
-#pragma unroll
-            for (int j = 1; j < 8; ++j) og = g >= j ? off[j] : og;
-            const int qi = valid ? t - og : 0;
-            const int r = valid ? reinterpret_cast<volatile int*>(&s_queue[wave][g][0])[qi] : -1;
-            if (r >= 0) {
-                const float4* pb = reinterpret_cast<const float4*>(P.rowsB + (size_t)r * DIMP);
-                const float4* pa = reinterpret_cast<const float4*>(&s_a[wave][g][0]);
-                float4 b[8], bn[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) b[u] = pb[u];
-                float d = 0.0f;
-#pragma unroll 1
-                for (int blk = 0; blk < NBLK; ++blk) {
-                    if (blk + 1 < NBLK) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) bn[u] = pb[(blk + 1) * 8 + u];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const float4 av = pa[blk * 8 + u];
-                        d = fmaf(b[u].x, av.x, d);
-                        d = fmaf(b[u].y, av.y, d);
-                        d = fmaf(b[u].z, av.z, d);
-                        d = fmaf(b[u].w, av.w, d);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) b[u] = bn[u];
-                }
-                const float sc = l2 ? fmaf(2.0f, d, -pr.nrmB[r]) : d;
-                reinterpret_cast<volatile float*>(&s_score[wave][g][0])[qi] = sc;
-            } else if (valid) {
-                reinterpret_cast<volatile float*>(&s_score[wave][g][0])[qi] = -INFINITY;   // a padding row of the last tile
-            }
-        }
-        for (int q = 0; q < nq; ++q) {
-            const float sc = score[q];
-            if (sc > -INFINITY) best2_insert(best, sc, queue[q]);
+            const float sc = l2 ? fmaf(2.0f, d, -nbr) : d;
+            if (act && sc > -INFINITY) best2_insert(best, sc, row);
         }
         nq = 0;
-        }
     };
 
     for (int sid = 0; sid < nsub; ++sid) {
@@ -828,12 +761,62 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
         }
     }
     score_all();
+    if (l2) {
+        // L2 results in difference form, as f32_l2_finish_kernel states them: the two rows found by the key are
+        // ordered by the k-ascending fmaf chain of (a[k] - b[k])^2 (lower row first when equal) and those
+        // distances are reported.  The query's columns are in registers and both rows were read a moment ago.
+        const bool has1 = best.r1 >= 0, has2 = best.r2 >= 0;
+        const float4* p1 = reinterpret_cast<const float4*>(P.rowsB + (size_t)(has1 ? best.r1 : 0) * DIMP) + sub * Q;
+        const float4* p2 = reinterpret_cast<const float4*>(P.rowsB + (size_t)(has2 ? best.r2 : (has1 ? best.r1 : 0)) * DIMP) + sub * Q;
+        float4 x[Q], y[Q];
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {
+            x[u] = p1[u];
+            y[u] = p2[u];
+        }
+        float d1 = 0.0f, d2 = 0.0f;
+#pragma unroll
+        for (int stage = 0; stage < 8; ++stage) {
+            if (sub == stage) {
+#pragma unroll
+                for (int u = 0; u < Q; ++u) {
+                    float t;
+                    t = areg[u].x - x[u].x; d1 = fmaf(t, t, d1);
+                    t = areg[u].y - x[u].y; d1 = fmaf(t, t, d1);
+                    t = areg[u].z - x[u].z; d1 = fmaf(t, t, d1);
+                    t = areg[u].w - x[u].w; d1 = fmaf(t, t, d1);
+                    t = areg[u].x - y[u].x; d2 = fmaf(t, t, d2);
+                    t = areg[u].y - y[u].y; d2 = fmaf(t, t, d2);
+                    t = areg[u].z - y[u].z; d2 = fmaf(t, t, d2);
+                    t = areg[u].w - y[u].w; d2 = fmaf(t, t, d2);
+                }
+            }
+            const float h1 = __shfl(d1, gbase + stage), h2 = __shfl(d2, gbase + stage);
+            if (sub == stage + 1 || stage == 7) {
+                d1 = h1;
+                d2 = h2;
+            }
+        }
+        if (live && sub == 0) {
+            const int64_t o = P.out_off + i;
+            int a1 = best.r1, a2 = best.r2;
+            if (has2 && (d2 < d1 || (d2 == d1 && a2 < a1))) {
+                const float t = d1; d1 = d2; d2 = t;
+                const int u = a1; a1 = a2; a2 = u;
+            }
+            j1_all[o] = a1;
+            j2_all[o] = a2;
+            k1_all[o] = has1 ? d1 : INFINITY;
+            k2_all[o] = has2 ? d2 : INFINITY;
+        }
+        return;
+    }
     if (live && sub == 0) {
         const int64_t o = P.out_off + i;
         j1_all[o] = best.r1;
         j2_all[o] = best.r2;
-        k1_all[o] = best.r1 < 0 ? (l2 ? INFINITY : -INFINITY) : (l2 ? fmaxf(-best.s1 + na, 0.0f) : best.s1);
-        k2_all[o] = best.r2 < 0 ? (l2 ? INFINITY : -INFINITY) : (l2 ? fmaxf(-best.s2 + na, 0.0f) : best.s2);
+        k1_all[o] = best.r1 < 0 ? -INFINITY : best.s1;
+        k2_all[o] = best.r2 < 0 ? -INFINITY : best.s2;
     }
 }
 
@@ -900,40 +883,34 @@ static void launch_coarse_d(const CoarseProblem* d_probs, int nprobs, int blocks
     }
 }
 
-void launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
+bool launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
                        int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow,
                        hipStream_t s, bool top1, bool db_lists)
 {
-    if (nprobs <= 0 || t.coarse_blocks <= 0) return;
+    if (nprobs <= 0 || t.coarse_blocks <= 0) return false;
     CoarsePart* part = static_cast<CoarsePart*>(scratch);
     uint2* lists = reinterpret_cast<uint2*>(static_cast<char*>(scratch) + part_bytes(t.sublists));
     const int dimp = f32_dimp(dim);
     if (dimp == 64) launch_coarse_d<64>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s, top1, db_lists);
     else if (dimp == 128) launch_coarse_d<128>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s, top1, db_lists);
     else launch_coarse_d<256>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s, top1, db_lists);
-    if (t.rerank_blocks <= 0) return;
+    if (t.rerank_blocks <= 0) return false;
     // many queries with few sublists each: eight queries per wave; few queries with many sublists
     // (a sliced database): one wave per query
     const bool grouped = t.max_nsplits * 2 <= 16 && (int64_t)t.rerank_blocks * nprobs >= 4096;
     if (grouped) {
         const int per = kGroupQueries / kRerankWaves;
         const dim3 grid((t.rerank_blocks + per - 1) / per, nprobs), block(kGroupWaves * 64);
-        // top-1 searches leave one or two rows per query: the eight-lane chain; else a (query, row) pair per lane
-        if (top1) {
-            if (dimp == 64) hipLaunchKernelGGL((bf16_rerank_group_kernel<64, true>), grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
-            else if (dimp == 128) hipLaunchKernelGGL((bf16_rerank_group_kernel<128, true>), grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
-            else hipLaunchKernelGGL((bf16_rerank_group_kernel<256, true>), grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
-        } else {
-            if (dimp == 64) hipLaunchKernelGGL((bf16_rerank_group_kernel<64, false>), grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
-            else if (dimp == 128) hipLaunchKernelGGL((bf16_rerank_group_kernel<128, false>), grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
-            else hipLaunchKernelGGL((bf16_rerank_group_kernel<256, false>), grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
-        }
+        if (dimp == 64) hipLaunchKernelGGL(bf16_rerank_group_kernel<64>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+        else if (dimp == 128) hipLaunchKernelGGL(bf16_rerank_group_kernel<128>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+        else hipLaunchKernelGGL(bf16_rerank_group_kernel<256>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
     } else {
         const dim3 grid(t.rerank_blocks, nprobs), block(kRerankWaves * 64);
         if (dimp == 64) hipLaunchKernelGGL(bf16_rerank_kernel<64>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
         else if (dimp == 128) hipLaunchKernelGGL(bf16_rerank_kernel<128>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
         else hipLaunchKernelGGL(bf16_rerank_kernel<256>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
     }
+    return grouped;   // the grouped kernel leaves L2 results in difference form already
 }
 
 }  // namespace vsm

@@ -120,7 +120,9 @@ size_t coarse_scratch_bytes(const CoarseTotals& t);
 // All problems must share f32_dimp(dim), top1 and whether they carry a database list.  Outputs as launch_f32_knn's query side at out_off, bit for
 // bit, PROVIDED *overflow (device int, cleared by the caller) reads 0 afterwards; a set flag means a
 // survivor list was too short and the results are void.
-void launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
+// Returns true when L2 results are already ordered and reported in difference form (launch_f32_l2_finish is
+// then not needed), false when they are still keys.
+bool launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
                        int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow,
                        hipStream_t s, bool top1 = false, bool db_lists = false);
 

@@ -781,10 +781,10 @@ int queue_coarse(vsm_ctx* c, std::vector<CoarseProblem>& probs, int dim, size_t 
     if (extra_dev) *extra_dev = c->d_probs.as<char>() + 256 + pbytes;
     if (probs.empty()) return VSM_OK;
     const CoarseProblem* d_probs = reinterpret_cast<const CoarseProblem*>(c->d_probs.as<char>() + 256);
-    launch_bf16_batch(d_probs, (int)probs.size(), dim, t,
+    const bool finished = launch_bf16_batch(d_probs, (int)probs.size(), dim, t,
                       c->d_knnj.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_knn1.as<float>(), c->d_knn2.as<float>(),
                       c->d_coarse.p, c->flag_dev, c->stream);
-    if (probs[0].pr.metric == VSM_METRIC_L2) {   // one metric per submission
+    if (probs[0].pr.metric == VSM_METRIC_L2 && !finished) {   // one metric per submission
         int max_rows = 0;
         for (const CoarseProblem& p : probs) max_rows = std::max(max_rows, p.pr.nA);
         launch_f32_l2_finish(d_probs, (int)probs.size(), max_rows, nullptr, c->d_knnj.as<int32_t>(), c->d_rrj.as<int32_t>(),
@@ -1091,8 +1091,8 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     float* k2 = c->d_knn2.as<float>();
     auto search = [&](const CoarseProblem* dp, const CoarseProblem* hp, int n, const CoarseTotals& t, bool lists) {
         if (n <= 0) return;
-        launch_bf16_batch(dp, n, pl.dim, t, j1, j2, k1, k2, c->d_coarse.p, c->flag_dev, c->stream, dot, lists);
-        if (!dot) {
+        const bool finished = launch_bf16_batch(dp, n, pl.dim, t, j1, j2, k1, k2, c->d_coarse.p, c->flag_dev, c->stream, dot, lists);
+        if (!dot && !finished) {
             int max_rows = 0;
             for (int i = 0; i < n; ++i) max_rows = std::max(max_rows, hp[i].pr.nA);
             launch_f32_l2_finish(dp, n, max_rows, nullptr, j1, j2, k1, k2, c->stream);
