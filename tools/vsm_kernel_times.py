@@ -7,6 +7,6 @@ for row in csv.DictReader(open(sys.argv[1])):
     name = row["Name"]
     if "vsm::" not in name:
         continue
-    short = name.split("vsm::", 1)[1].split("(", 1)[0]
+    short = name.split("vsm::", 1)[1].replace("(anonymous namespace)::", "").split("(", 1)[0]
     print("%-44s calls %5s  avg %9.3f us  total %9.3f ms" % (short, row["Calls"], float(row["AverageNs"]) / 1e3,
                                                             float(row["TotalDurationNs"]) / 1e6))
