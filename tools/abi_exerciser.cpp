@@ -98,7 +98,13 @@ int main()
             const int32_t fp[] = {f0, f1, f1, f0, f0, f0};
             std::vector<int64_t> fo(4);
             std::vector<int32_t> u0(3 * r), u1(3 * r);
-            CHECK(vsm_match_pairs(ctx, fp, 3, &pf, VSM_METRIC_DOT, fo.data(), u0.data(), u1.data(), 3 * r));
+            for (int rev : {VSM_F32_REVERSE_ALL, VSM_F32_REVERSE_CANDIDATES, VSM_F32_REVERSE_AUTO}) {
+                CHECK(vsm_set_f32_reverse(ctx, rev));
+                CHECK(vsm_match_pairs(ctx, fp, 3, &pf, VSM_METRIC_DOT, fo.data(), u0.data(), u1.data(), 3 * r));
+                vsm_params pl = pf;
+                pl.ratio_num = 4; pl.ratio_den = 5;
+                CHECK(vsm_match_pairs(ctx, fp, 3, &pl, VSM_METRIC_L2, fo.data(), u0.data(), u1.data(), 3 * r));
+            }
         }
         CHECK(vsm_set_f32_mode(ctx, VSM_F32_FAST_EXACT));
         // sliced database: device-resident per-slice results, device merge
