@@ -769,7 +769,7 @@ def run_db_query(args, torch, dist, world, rank):
         "roofline": f32_roofline(m, OPS_PER_EVAL_F32 * float(nq) * (hi - lo), kms),
     }
     if world == 1 and m.last_f32_path() == 0:   # the counter passes were taken at this shape
-        out["roofline"]["traffic"] = measured_traffic("void vsm::bf16_coarse_kernel<256>", "r02_traffic_db_query.json")
+        out["roofline"]["traffic"] = measured_traffic("void vsm::bf16_coarse_kernel<256, false, false>", "r02_traffic_db_query.json")
     m.close()
     return out
 
