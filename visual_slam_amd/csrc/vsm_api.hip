@@ -100,6 +100,10 @@ struct vsm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     unsigned char* noalloc_scratch = nullptr;   // this device's copy of `scratch`
+    // Workgroups a float search is cut into when its database is long enough: two per CU, i.e. the coarse grid
+    // is resident all at once (512 on a whole MI355X; twice as many ran 2.5 % slower on the 16384 x 1M query:
+    // half as long survivor sublists, whose thresholds are young for a larger share of their tiles)
+    int coarse_wgs = 512;
     std::string err;
     std::vector<DescSet> sets;
     // workspace (grow-only)
@@ -474,6 +478,7 @@ extern "C" vsm_ctx* vsm_create(int device)
     vsm_ctx* c = new vsm_ctx();
     c->device = device;
     c->noalloc_scratch = scratch_dev;
+    c->coarse_wgs = std::max(2 * prop.multiProcessorCount, 64);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->slots[0].ev0)) != hipSuccess || (e = hipEventCreate(&c->slots[0].ev1)) != hipSuccess ||
         (e = hipEventCreate(&c->slots[0].ev2)) != hipSuccess || (e = hipEventCreate(&c->slots[0].ev3)) != hipSuccess ||
@@ -759,7 +764,7 @@ CoarseProblem make_problem(const DescSet* A, const DescSet* B, int metric)
 int queue_coarse(vsm_ctx* c, std::vector<CoarseProblem>& probs, int dim, size_t min_rows, size_t extra_bytes = 0,
                  const std::function<void(char*)>& fill_extra = nullptr, char** extra_dev = nullptr)
 {
-    const CoarseTotals t = plan_coarse(probs.data(), (int)probs.size(), 1024);
+    const CoarseTotals t = plan_coarse(probs.data(), (int)probs.size(), c->coarse_wgs);
     const size_t rows = std::max<size_t>(std::max<size_t>((size_t)t.out_rows, min_rows), 1);
     HIPCHK(c, c->d_knnj.ensure(rows * 4));
     HIPCHK(c, c->d_rrj.ensure(rows * 4));
@@ -1044,10 +1049,10 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     // geometry and offsets: one group when both directions go in one launch, else two
     CoarseTotals t1, t2;
     if (two_phase) {
-        t1 = plan_coarse(pl.probs.data(), nfwd, 1024);
-        t2 = plan_coarse(pl.probs.data() + nfwd, nrev, 1024, t1.out_rows);
+        t1 = plan_coarse(pl.probs.data(), nfwd, c->coarse_wgs);
+        t2 = plan_coarse(pl.probs.data() + nfwd, nrev, c->coarse_wgs, t1.out_rows);
     } else {
-        t1 = plan_coarse(pl.probs.data(), nprobs, 1024);
+        t1 = plan_coarse(pl.probs.data(), nprobs, c->coarse_wgs);
         t2 = t1;
     }
     const size_t rows = std::max<size_t>((size_t)t2.out_rows, 1);
