@@ -574,24 +574,38 @@ void sift_merge_chunks_kernel(const SiftPair* __restrict__ pairs, int32_t* __res
     *reinterpret_cast<int4*>(rr_k2 + o) = y2;
 }
 
+// One workgroup per (pair, slice of its rows); slices exist so that a pair of many rows is not walked by a single
+// workgroup (65536 rows: 63 us on one CU).  Candidates must come out in ascending row order, so a sliced launch
+// runs twice: COUNT = true leaves the number of candidates of every slice in slice_counts[pair * slices + slice],
+// COUNT = false starts each slice's output behind the slices before it.  With one slice per pair only the second
+// form runs.  Slice s of a pair holds rows [s * span, (s + 1) * span), span = the pair's rows over the slices,
+// rounded up to whole rounds of the workgroup.
+template <bool COUNT>
 __global__ __launch_bounds__(1024)
 void sift_select_tile_kernel(const SiftPair* __restrict__ pairs,
                              int32_t* __restrict__ rr_y1, const int32_t* __restrict__ rr_tile,
-                             const int32_t* __restrict__ rr_k2, int merged, MatchRule rule, SiftCandidates cand)
+                             const int32_t* __restrict__ rr_k2, int merged, MatchRule rule, SiftCandidates cand,
+                             int32_t* __restrict__ slice_counts)
 {
     __shared__ int wsum[16];
     __shared__ int base_s;
-    const SiftPair pw = pairs[blockIdx.x];
+    constexpr int R = 8;
+    const int pair = blockIdx.y, sl = blockIdx.x, nsl = gridDim.x;
+    const SiftPair pw = pairs[pair];
     const int tid = threadIdx.x;
+    const int span = ((pw.nA + nsl - 1) / nsl + 1024 * R - 1) / (1024 * R) * (1024 * R);
+    const int lo = min(sl * span, pw.nA), hi = min(lo + span, pw.nA);
     if (tid == 0) {
-        base_s = 0;
-        cand.dmax[blockIdx.x] = INT32_MIN;
+        int base = 0;
+        if (!COUNT)
+            for (int k = 0; k < sl; ++k) base += slice_counts[pair * nsl + k];
+        base_s = base;
+        if (!COUNT && sl == 0) cand.dmax[pair] = INT32_MIN;
     }
-    if (blockIdx.x == 0 && tid == 0) *cand.rescan_count = 0;
+    if (!COUNT && pair == 0 && sl == 0 && tid == 0) *cand.rescan_count = 0;
     __syncthreads();
 
-    constexpr int R = 8;
-    for (int i0 = 0; i0 < pw.nA; i0 += 1024 * R) {
+    for (int i0 = lo; i0 < hi; i0 += 1024 * R) {
         const int ib = i0 + tid * R;
         int tl[R], y1[R], y2[R];
 #pragma unroll
@@ -613,8 +627,9 @@ void sift_select_tile_kernel(const SiftPair* __restrict__ pairs,
 #pragma unroll
                 for (int r = 0; r < R; ++r) merge_chunk_row(e1[r], et[r], e2[r], y1[r], tl[r], y2[r]);
             }
-            if (nchunks > 1) {
+            if (!COUNT && nchunks > 1) {
                 // the merged half-distances stay in chunk 0's records: sift_verify_rows_kernel reads them
+                // (not in the counting launch: the second launch merges the same records again)
                 int32_t* dst = rr_y1 + pw.row_off + ib;
                 *reinterpret_cast<int4*>(dst) = make_int4(y1[0], y1[1], y1[2], y1[3]);
                 *reinterpret_cast<int4*>(dst + 4) = make_int4(y1[4], y1[5], y1[6], y1[7]);
@@ -636,6 +651,7 @@ void sift_select_tile_kernel(const SiftPair* __restrict__ pairs,
             okbits |= (ok ? 1u : 0u) << r;
         }
         int slot = block_compact_range(__popc(okbits), wsum, &base_s);
+        if (COUNT) continue;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if ((okbits >> r) & 1u) {
@@ -649,11 +665,18 @@ void sift_select_tile_kernel(const SiftPair* __restrict__ pairs,
         }
     }
     __syncthreads();
-    if (tid == 0) cand.count[blockIdx.x] = base_s;
+    if (tid == 0) {
+        if (COUNT) slice_counts[pair * nsl + sl] = base_s;
+        else if (sl == nsl - 1) cand.count[pair] = base_s;
+    }
 }
 
+int sift_select_slices(int max_rows) { return std::max(1, std::min(kMaxRowSlices, (max_rows + 8191) / 8192)); }
+int sift_verify_rows_slices(int max_rows) { return std::max(1, std::min(kMaxRowSlices, (max_rows + 4095) / 4096)); }
+
 void launch_sift_select_tile(const SiftPair* pairs, int npairs, int max_rows, int max_chunks, int32_t* rr_y1,
-                             int32_t* rr_tile, int32_t* rr_k2, MatchRule rule, SiftCandidates cand, hipStream_t s)
+                             int32_t* rr_tile, int32_t* rr_k2, MatchRule rule, SiftCandidates cand,
+                             int32_t* slice_counts, hipStream_t s)
 {
     // a merged record of a one-chunk pair is the record itself; a first tie between chunks that the merge
     // turned into y2 == y1 stays one when the select pass reads the merged record
@@ -661,8 +684,12 @@ void launch_sift_select_tile(const SiftPair* pairs, int npairs, int max_rows, in
     if (merge)
         hipLaunchKernelGGL(sift_merge_chunks_kernel, dim3((max_rows + 1023) / 1024, npairs), dim3(256), 0, s,
                            pairs, rr_y1, rr_tile, rr_k2);
-    hipLaunchKernelGGL(sift_select_tile_kernel, dim3(npairs), dim3(1024), 0, s,
-                       pairs, rr_y1, rr_tile, rr_k2, merge ? 1 : 0, rule, cand);
+    const dim3 grid(sift_select_slices(max_rows), npairs);
+    if (grid.x > 1)
+        hipLaunchKernelGGL(sift_select_tile_kernel<true>, grid, dim3(1024), 0, s,
+                           pairs, rr_y1, rr_tile, rr_k2, merge ? 1 : 0, rule, cand, slice_counts);
+    hipLaunchKernelGGL(sift_select_tile_kernel<false>, grid, dim3(1024), 0, s,
+                       pairs, rr_y1, rr_tile, rr_k2, merge ? 1 : 0, rule, cand, slice_counts);
 }
 
 // ---- 2c. resolve / rescan ------------------------------------------------------------------
@@ -843,18 +870,29 @@ void sift_rescan_kernel(const SiftPair* __restrict__ pairs, MatchRule rule, Sift
 }
 
 // The image-0 rows that can matter to the mutual check of a pair (see SiftCandidates::dmax), in ascending order.
+// Sliced like sift_select_tile_kernel: a counting launch first when a pair's rows are cut into several slices.
+template <bool COUNT>
 __global__ __launch_bounds__(1024)
-void sift_verify_rows_kernel(const SiftPair* __restrict__ pairs, const int32_t* __restrict__ rr_y1, SiftCandidates cand)
+void sift_verify_rows_kernel(const SiftPair* __restrict__ pairs, const int32_t* __restrict__ rr_y1, SiftCandidates cand,
+                             int32_t* __restrict__ slice_counts)
 {
     __shared__ int wsum[16];
     __shared__ int base_s;
-    const SiftPair pw = pairs[blockIdx.x];
-    const int tid = threadIdx.x;
-    if (tid == 0) base_s = 0;
-    __syncthreads();
-    const long long dmax = cand.dmax[blockIdx.x];
     constexpr int R = 4;
-    for (int i0 = 0; i0 < pw.nA; i0 += 1024 * R) {
+    const int pair = blockIdx.y, sl = blockIdx.x, nsl = gridDim.x;
+    const SiftPair pw = pairs[pair];
+    const int tid = threadIdx.x;
+    const int span = ((pw.nA + nsl - 1) / nsl + 1024 * R - 1) / (1024 * R) * (1024 * R);
+    const int lo = min(sl * span, pw.nA), hi = min(lo + span, pw.nA);
+    if (tid == 0) {
+        int base = 0;
+        if (!COUNT)
+            for (int k = 0; k < sl; ++k) base += slice_counts[pair * nsl + k];
+        base_s = base;
+    }
+    __syncthreads();
+    const long long dmax = cand.dmax[pair];
+    for (int i0 = lo; i0 < hi; i0 += 1024 * R) {
         const int ib = i0 + tid * R;
         unsigned okbits = 0;
         int nn_keep[R] = {0, 0, 0, 0};
@@ -869,6 +907,7 @@ void sift_verify_rows_kernel(const SiftPair* __restrict__ pairs, const int32_t* 
             }
         }
         int slot = block_compact_range(__popc(okbits), wsum, &base_s);
+        if (COUNT) continue;
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if ((okbits >> r) & 1u) {
@@ -879,14 +918,20 @@ void sift_verify_rows_kernel(const SiftPair* __restrict__ pairs, const int32_t* 
             }
     }
     __syncthreads();
-    if (tid == 0) cand.nvrows[blockIdx.x] = base_s;
+    if (tid == 0) {
+        if (COUNT) slice_counts[pair * nsl + sl] = base_s;
+        else if (sl == nsl - 1) cand.nvrows[pair] = base_s;
+    }
 }
 
-void launch_sift_verify_rows(const SiftPair* pairs, int npairs, const int32_t* rr_y1, SiftCandidates cand,
-                             hipStream_t s)
+void launch_sift_verify_rows(const SiftPair* pairs, int npairs, int max_rows, const int32_t* rr_y1, SiftCandidates cand,
+                             int32_t* slice_counts, hipStream_t s)
 {
     if (npairs <= 0) return;
-    hipLaunchKernelGGL(sift_verify_rows_kernel, dim3(npairs), dim3(1024), 0, s, pairs, rr_y1, cand);
+    const dim3 grid(sift_verify_rows_slices(max_rows), npairs);
+    if (grid.x > 1)
+        hipLaunchKernelGGL(sift_verify_rows_kernel<true>, grid, dim3(1024), 0, s, pairs, rr_y1, cand, slice_counts);
+    hipLaunchKernelGGL(sift_verify_rows_kernel<false>, grid, dim3(1024), 0, s, pairs, rr_y1, cand, slice_counts);
 }
 
 void launch_sift_resolve(const SiftPair* pairs, int npairs, int max_rows, MatchRule rule, SiftCandidates cand,

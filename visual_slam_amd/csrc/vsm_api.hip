@@ -285,7 +285,14 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     HIPCHK(c, c->d_rr2.ensure(rows * 4));
     // vbest (8) + i0, j1, d1, aux (4 each) + rescan list (8) + row list of the verify pass (4 + 4) per row, then
     // per-pair counts, largest accepted distances and row-list lengths, and the rescan counter
-    HIPCHK(c, c->d_cand.ensure(out0 * 40 + sizeof(int32_t) * (3 * std::max(npairs, 1) + 16)));
+    // and the per-slice counts of the select and row-list passes (pairs of many rows are cut into slices)
+    int max_rows = 0, max_chunks = 0;
+    for (const SiftPair& sp : pl.pairs) {
+        max_rows = std::max(max_rows, sp.nA);
+        max_chunks = std::max(max_chunks, sp.nchunks);
+    }
+    const int slice_ints = std::max(sift_select_slices(max_rows), sift_verify_rows_slices(max_rows));
+    HIPCHK(c, c->d_cand.ensure(out0 * 40 + sizeof(int32_t) * ((3 + (size_t)slice_ints) * std::max(npairs, 1) + 16)));
     if (!c->d_zero_tile.p) {
         HIPCHK(c, c->d_zero_tile.ensure(kTileBytes));
         HIPCHK(c, hipMemsetAsync(c->d_zero_tile.p, 0, kTileBytes, c->stream));
@@ -355,6 +362,7 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
         int32_t* dmax = cand.count + std::max(npairs, 1);
         int32_t* nvrows = dmax + std::max(npairs, 1);
         cand.rescan_count = nvrows + std::max(npairs, 1);
+        int32_t* slice_counts = cand.rescan_count + 16;
         if (tile_path) {   // the packed path has no bound on the rows that matter: its verify pass streams them all
             cand.dmax = dmax;
             cand.vrows = row_list;
@@ -377,15 +385,12 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
             out.knn_d2 = c->d_knn2.as<int32_t>();
         }
         if (tile_path) {
-            int max_rows = 0, max_chunks = 0;
-            for (const SiftPair& sp : pl.pairs) {
-                max_rows = std::max(max_rows, sp.nA);
-                max_chunks = std::max(max_chunks, sp.nchunks);
-            }
             launch_sift_select_tile(c->d_pairs.as<SiftPair>(), npairs, max_rows, max_chunks, c->d_rr1.as<int32_t>(),
-                                    c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, c->stream);
+                                    c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, slice_counts, c->stream);
             launch_sift_resolve(c->d_pairs.as<SiftPair>(), npairs, max_rows, rule, cand, c->stream);
-            if (nvitems) launch_sift_verify_rows(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(), cand, c->stream);
+            if (nvitems)
+                launch_sift_verify_rows(c->d_pairs.as<SiftPair>(), npairs, max_rows, c->d_rr1.as<int32_t>(), cand,
+                                        slice_counts, c->stream);
         } else {
             launch_sift_select(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(),
                                c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, out, c->stream);

@@ -197,12 +197,19 @@ void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
 // cannot settle.
 void launch_sift_query_tile(const SiftPair* pairs, const SiftItem* items, int nitems,
                             int32_t* rr_y1, int32_t* rr_tile, int32_t* rr_k2, hipStream_t s);
+// slice_counts: sift_select_slices(max_rows) ints per pair of scratch (a pair of many rows is cut into slices, each
+// with a workgroup of its own; untouched when there is one slice).
+constexpr int kMaxRowSlices = 64;
+int sift_select_slices(int max_rows);
+int sift_verify_rows_slices(int max_rows);
 void launch_sift_select_tile(const SiftPair* pairs, int npairs, int max_rows, int max_chunks, int32_t* rr_y1,
-                             int32_t* rr_tile, int32_t* rr_k2, MatchRule rule, SiftCandidates cand, hipStream_t s);
+                             int32_t* rr_tile, int32_t* rr_k2, MatchRule rule, SiftCandidates cand,
+                             int32_t* slice_counts, hipStream_t s);
 // After the resolve pass: cand.vrows / cand.nvrows from the merged half-distances the select pass left in
 // chunk 0's records of rr_y1.
-void launch_sift_verify_rows(const SiftPair* pairs, int npairs, const int32_t* rr_y1, SiftCandidates cand,
-                             hipStream_t s);
+// slice_counts: sift_verify_rows_slices(max_rows) ints per pair of scratch.
+void launch_sift_verify_rows(const SiftPair* pairs, int npairs, int max_rows, const int32_t* rr_y1, SiftCandidates cand,
+                             int32_t* slice_counts, hipStream_t s);
 void launch_sift_resolve(const SiftPair* pairs, int npairs, int max_rows, MatchRule rule, SiftCandidates cand,
                          hipStream_t s);
 // chunk merge + distance/ratio tests -> candidate lists (+ raw 2-NN outputs)
