@@ -415,3 +415,40 @@ def test_distance_cap_with_ratio(matcher):
     finally:
         matcher.release(s0)
         matcher.release(s1)
+
+
+def test_pairs_of_many_rows_are_cut_into_slices(matcher):
+    """Image-0 sets above 8192 rows: the select and row-list passes cut such a pair's rows into slices with a
+    workgroup each, and the candidates must still come out in ascending row order.  Rows shared between the
+    images put candidates into every slice; the list mixes the large pairs with small and empty ones, whose slices past
+    the end of their rows do nothing."""
+    rng = np.random.default_rng(4242)
+    pool = synth.sift_like(40000, rng)
+    sizes = [20000, 0, 9000, 1, 33000, 700]
+    imgs = []
+    for n in sizes:
+        x = synth.sift_like(n, rng)
+        k = n // 3
+        if k:
+            # every image holds noisy copies of its own choice of pool rows, each at most once
+            x[rng.choice(n, k, replace=False)] = np.clip(
+                pool[rng.choice(40000, k, replace=False)].astype(np.int32) + rng.integers(-3, 4, (k, 128)), 0, 255).astype(np.uint8)
+        imgs.append(x)
+    ids = [matcher.upload_u8(x) for x in imgs]
+    pairs = [(0, 5), (1, 0), (4, 2), (3, 4), (2, 0), (5, 4), (4, 5), (0, 1)]
+    try:
+        for mutual in (True, False):
+            off, i0, i1 = matcher.match_pairs([[ids[i], ids[j]] for i, j in pairs], ratio=0.8, mutual=mutual)
+            for k, (i, j) in enumerate(pairs):
+                o0, o1, _ = orc.match_u8(imgs[i], imgs[j], orc.params((4, 5), mutual))
+                np.testing.assert_array_equal(i0[off[k]:off[k + 1]], o0)
+                np.testing.assert_array_equal(i1[off[k]:off[k + 1]], o1)
+        g0, g1, gd = matcher.match_pair(ids[4], ids[0], ratio=0.8, mutual=True, return_dist=True)
+        o0, o1, od = orc.match_u8(imgs[4], imgs[0], orc.params((4, 5), True))
+        assert len(o0) > 1000
+        np.testing.assert_array_equal(g0, o0)
+        np.testing.assert_array_equal(g1, o1)
+        np.testing.assert_array_equal(gd, od)
+    finally:
+        for s in ids:
+            matcher.release(s)

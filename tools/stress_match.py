@@ -58,7 +58,9 @@ def size(rng):
         return int(rng.choice([0, 1, 2, 31, 32, 33, 255, 256, 257, 511, 512, 513]))
     if r < 0.85:
         return int(rng.integers(1, 3000))
-    return int(rng.integers(3000, 9500))      # several chunks for a single pair, merged chunk records above 4096
+    if r < 0.97:
+        return int(rng.integers(3000, 9500))  # several chunks for a single pair, merged chunk records above 4096
+    return int(rng.integers(9500, 40000))     # several slices of the select and row-list passes
 
 
 def one_u8(m, rng):
