@@ -28,6 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 INT8_DENSE_PEAK_TOPS = 5000.0   # MI355X dense int8 MFMA, 2x the ~2.5 PFLOP/s bf16 figure
 F32_MFMA_PEAK_TFLOPS = 157.3    # f32-input MFMA (exact f32), = vector peak
 BF16_DENSE_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA
+HBM_PEAK_GBPS = 8000.0          # HBM3E
 
 
 def measured_traffic(kernel, summary="r02_traffic_sift_exhaustive.json"):
@@ -353,6 +354,10 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
                      "verify_kernel_ms": float(np.mean(verify_ms)),
                      "note": "int8 ops: 256 per descriptor pair (128 MAC), one direction counted once"},
     }
+    if out["roofline"]["traffic"]:
+        # the committed counter figure over this run's kernel time, against the 8 TB/s of HBM3E
+        out["roofline"]["hbm_gb_per_s"] = out["roofline"]["traffic"] / (kms * 1e-3) / 1e9
+        out["roofline"]["hbm_frac_of_peak"] = out["roofline"]["hbm_gb_per_s"] / HBM_PEAK_GBPS
     if world == 1 and not args.no_cpu_baseline:
         sets = [arena[i].cpu().numpy() for i in range(min(8, nimg))]
         out["cpu_baseline"] = cpu_baseline_u8(sets, args.cpu_seconds)
@@ -770,6 +775,12 @@ def run_db_query(args, torch, dist, world, rank):
     }
     if world == 1 and m.last_f32_path() == 0:   # the counter passes were taken at this shape
         out["roofline"]["traffic"] = measured_traffic("void vsm::bf16_coarse_kernel<256, false, false>", "r02_traffic_db_query.json")
+        if out["roofline"]["traffic"]:
+            out["roofline"]["traffic_note"] = ("HBM bytes per launch of the coarse kernel: a constant read from committed rocprofv3 "
+                                               "--pmc passes over the same search (profiles/r02_dbquery_pmc_*.csv), not a "
+                                               "measurement of this run")
+            out["roofline"]["hbm_gb_per_s"] = out["roofline"]["traffic"] / (kms * 1e-3) / 1e9
+            out["roofline"]["hbm_frac_of_peak"] = out["roofline"]["hbm_gb_per_s"] / HBM_PEAK_GBPS
     m.close()
     return out
 
