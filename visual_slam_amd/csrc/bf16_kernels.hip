@@ -15,6 +15,13 @@
 // rounding of partial sums of that size: 2 * 256 * 2^-24 * max|b|^2 / 2 on top of 2 eps.
 // Inputs are assumed finite and far from the ends of the f32 exponent range.
 //
+// Searches cut into several database splits share their thresholds: the splits of a query run side by side, each
+// with the running runner-up (top1: best) of its own rows only, which is young for a good part of a short split.
+// After tiles 4, 8, 16 and every 32 of its split a lane reads a word per query and, when its own value is better, publishes it
+// (atomic maximum over an order-preserving integer image of the float): any split's running runner-up is at most the
+// final T2, so (that value - margin) is a floor no survivor lies under.  Which entries get appended then depends on
+// timing; the survivors of the final threshold, and with them the results, do not.
+//
 // Two reductions of the work for callers that need less than the two best rows of every query:
 //  * top1: only the best row matters.  The threshold is then T1 - 2 eps (T1 = the largest coarse score): the
 //    exact best row scores at least what the coarse-best row scores exactly, which is >= T1 - eps, so its own
@@ -170,10 +177,22 @@ __device__ __forceinline__ int find_problem(int nprobs, int L, GetFirst first)
     return lo;
 }
 
+// order-preserving image of a float in an unsigned integer (0 is below every float, including -inf)
+__device__ __forceinline__ unsigned float_order_bits(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_of_order_bits(unsigned e)
+{
+    return e == 0 ? -INFINITY : __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+
 template <int DIMP, bool TOP1, bool DBL>
 __global__ __launch_bounds__(kCoarseWaves * 64, 2)
 void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
-                        CoarsePart* __restrict__ part_all, uint2* __restrict__ lists_all, int* __restrict__ overflow)
+                        CoarsePart* __restrict__ part_all, uint2* __restrict__ lists_all, int* __restrict__ overflow,
+                        unsigned* __restrict__ shared_thr, int64_t out_rows0)
 {
     constexpr int S = DIMP / 16;             // k-steps (MFMAs) per tile
     constexpr int RB = kCoarseRB;
@@ -215,6 +234,7 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
     v8bf qf[RB][S];
     float margin[RB], floorc[RB], thr[RB], b1[RB], b2[RB];
     int cnt[RB];
+    bool live[RB];
     const int qidx0 = ((strip * kCoarseWaves + wave) * RB) * 32 + lane5;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -244,7 +264,10 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
         b1[rb] = -INFINITY;
         b2[rb] = -INFINITY;
         cnt[rb] = 0;
+        live[rb] = real;
     }
+    // one word per query slot, shared by the splits of the search (cleared by the launcher); unused with one split
+    unsigned* __restrict__ shared_q = shared_thr && P.nsplits > 1 ? shared_thr + (P.out_off - out_rows0) + qidx0 : nullptr;
 
     const int32_t* __restrict__ dblist = P.dblist;
     const int ndb = DBL ? *P.dbcount : 0;
@@ -369,6 +392,20 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
                         lists[list_slot(mysub, cnt[rb])] =
                             make_uint2(((unsigned)(tile - t0) << 16) | rowbits, __float_as_uint(tmax));
                     ++cnt[rb];
+                }
+            }
+            const int rel = tile - t0;
+            if (shared_q && ((rel & 31) == 31 || rel == 3 || rel == 7 || rel == 15)) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    if (!live[rb]) continue;
+                    // read what the other splits have reached (past this CU's cache), publish only an improvement:
+                    // once the thresholds have settled the exchange is a load
+                    const float mine = TOP1 ? b1[rb] : b2[rb];
+                    const unsigned mybits = float_order_bits(mine);
+                    const unsigned seen = __hip_atomic_load(shared_q + rb * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (mybits > seen) atomicMax(shared_q + rb * 32, mybits);
+                    floorc[rb] = fmaxf(floorc[rb], fmaxf(float_of_order_bits(seen), mine) - margin[rb]);
                 }
             }
         }
@@ -831,6 +868,7 @@ CoarseTotals plan_coarse(CoarseProblem* probs, int n, int target_wgs, int64_t ou
     const int want = unsplit >= target_wgs || unsplit == 0 ? 1 : (int)((target_wgs + unsplit - 1) / unsplit);
     CoarseTotals t;
     t.out_rows = out_rows0;
+    t.out_rows0 = out_rows0;
     for (int i = 0; i < n; ++i) {
         CoarseProblem& p = probs[i];
         const int ntiles = p.pr.nB_pad / 32;
@@ -854,32 +892,35 @@ CoarseTotals plan_coarse(CoarseProblem* probs, int n, int target_wgs, int64_t ou
 
 static size_t part_bytes(int64_t sublists) { return ((size_t)sublists * sizeof(CoarsePart) + 255) & ~(size_t)255; }
 
+static size_t list_bytes(int64_t sublists) { return ((size_t)sublists * kCoarseCap * sizeof(uint2) + 255) & ~(size_t)255; }
+
+// [parts][lists][one shared-threshold word per output row of the group]
 size_t coarse_scratch_bytes(const CoarseTotals& t)
 {
-    return part_bytes(t.sublists) + (size_t)t.sublists * kCoarseCap * sizeof(uint2) + 256;
+    return part_bytes(t.sublists) + list_bytes(t.sublists) + (size_t)(t.out_rows - t.out_rows0) * sizeof(unsigned) + 256;
 }
 
 template <int DIMP, bool TOP1, bool DBL>
 static void launch_coarse_t(const CoarseProblem* d_probs, int nprobs, int blocks, CoarsePart* part, uint2* lists,
-                            int* overflow, hipStream_t s)
+                            int* overflow, unsigned* shared_thr, int64_t out_rows0, hipStream_t s)
 {
     const int lds = 2 * kCoarseStepBytes;
     static DeviceFlags attr_set;   // the attribute is per device (and per instantiation: one flag set each)
     ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(bf16_coarse_kernel<DIMP, TOP1, DBL>), lds);
     hipLaunchKernelGGL((bf16_coarse_kernel<DIMP, TOP1, DBL>), dim3(blocks), dim3(kCoarseWaves * 64), lds, s,
-                       d_probs, nprobs, part, lists, overflow);
+                       d_probs, nprobs, part, lists, overflow, shared_thr, out_rows0);
 }
 
 template <int DIMP>
 static void launch_coarse_d(const CoarseProblem* d_probs, int nprobs, int blocks, CoarsePart* part, uint2* lists,
-                            int* overflow, hipStream_t s, bool top1, bool db_lists)
+                            int* overflow, unsigned* shared_thr, int64_t out_rows0, hipStream_t s, bool top1, bool db_lists)
 {
     if (db_lists) {
-        if (top1) launch_coarse_t<DIMP, true, true>(d_probs, nprobs, blocks, part, lists, overflow, s);
-        else launch_coarse_t<DIMP, false, true>(d_probs, nprobs, blocks, part, lists, overflow, s);
+        if (top1) launch_coarse_t<DIMP, true, true>(d_probs, nprobs, blocks, part, lists, overflow, shared_thr, out_rows0, s);
+        else launch_coarse_t<DIMP, false, true>(d_probs, nprobs, blocks, part, lists, overflow, shared_thr, out_rows0, s);
     } else {
-        if (top1) launch_coarse_t<DIMP, true, false>(d_probs, nprobs, blocks, part, lists, overflow, s);
-        else launch_coarse_t<DIMP, false, false>(d_probs, nprobs, blocks, part, lists, overflow, s);
+        if (top1) launch_coarse_t<DIMP, true, false>(d_probs, nprobs, blocks, part, lists, overflow, shared_thr, out_rows0, s);
+        else launch_coarse_t<DIMP, false, false>(d_probs, nprobs, blocks, part, lists, overflow, shared_thr, out_rows0, s);
     }
 }
 
@@ -890,10 +931,13 @@ bool launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const 
     if (nprobs <= 0 || t.coarse_blocks <= 0) return false;
     CoarsePart* part = static_cast<CoarsePart*>(scratch);
     uint2* lists = reinterpret_cast<uint2*>(static_cast<char*>(scratch) + part_bytes(t.sublists));
+    unsigned* shared_thr = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lists) + list_bytes(t.sublists));
+    // the words the splits of a search share: 0 = nothing published yet
+    if (shared_thr && t.max_nsplits > 1) (void)hipMemsetAsync(shared_thr, 0, (size_t)(t.out_rows - t.out_rows0) * sizeof(unsigned), s);
     const int dimp = f32_dimp(dim);
-    if (dimp == 64) launch_coarse_d<64>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s, top1, db_lists);
-    else if (dimp == 128) launch_coarse_d<128>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s, top1, db_lists);
-    else launch_coarse_d<256>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, s, top1, db_lists);
+    if (dimp == 64) launch_coarse_d<64>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s, top1, db_lists);
+    else if (dimp == 128) launch_coarse_d<128>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s, top1, db_lists);
+    else launch_coarse_d<256>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s, top1, db_lists);
     if (t.rerank_blocks <= 0) return false;
     // many queries with few sublists each: eight queries per wave; few queries with many sublists
     // (a sliced database): one wave per query

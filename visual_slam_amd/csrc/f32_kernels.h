@@ -110,6 +110,7 @@ struct CoarseTotals {
     int rerank_blocks = 0;   // query blocks of the largest problem (grid x of the re-rank)
     int max_nsplits = 0;     // most database splits any problem has (picks the re-rank kernel)
     int64_t sublists = 0, out_rows = 0;
+    int64_t out_rows0 = 0;   // first output row of the group (out_rows - out_rows0 rows belong to it)
 };
 
 // Fills the geometry and offsets of n problems (pr, bf*, initB, maxnormB_sq already set) so that the
