@@ -83,6 +83,39 @@ def test_ties_first_index(matcher):
         _knn_check(matcher, a, b, metric)
 
 
+def test_two_best_rows_inside_one_group_of_a_tile(matcher):
+    """A lane of the coarse pass keeps its runner-up over tile maxima (the 16 rows of a tile it holds), not over
+    rows: when a query's two best rows are among those 16 rows its threshold stays below the runner-up over rows,
+    and both rows must still come out, in order.  Rows 1 and 2 of a tile belong to one lane, rows 1 and 5 to two."""
+    rng = np.random.default_rng(77)
+    nq = 300
+    a = synth.unit_f32(nq, 256, rng)
+    b = synth.unit_f32(nq * 32 + 40, 256, rng)
+    want1 = np.empty(nq, np.int32)
+    want2 = np.empty(nq, np.int32)
+    for q in range(nq):
+        j1, j2 = 32 * q + 1, 32 * q + (2 if q % 2 == 0 else 5)
+        if q % 3 == 0:
+            j1, j2 = j2, j1          # the better row may come second in the tile
+        for j, noise in ((j1, 0.01), (j2, 0.03)):
+            v = a[q] + noise * rng.standard_normal(256).astype(np.float32)
+            b[j] = v / np.linalg.norm(v)
+        want1[q], want2[q] = j1, j2
+    s0, s1 = matcher.upload_f32(a), matcher.upload_f32(b)
+    try:
+        for metric in (vsm.METRIC_DOT, vsm.METRIC_L2):
+            gi1, gi2, gk1, gk2 = matcher.knn2(s0, s1, metric, want_idx2=True)
+            oi, ok1, ok2 = orc.knn2_f32(a, b, metric)
+            np.testing.assert_array_equal(oi, want1)
+            np.testing.assert_array_equal(gi1, want1)
+            np.testing.assert_array_equal(gi2, want2)
+            np.testing.assert_array_equal(gk1, ok1)
+            np.testing.assert_array_equal(gk2, ok2)
+    finally:
+        matcher.release(s0)
+        matcher.release(s1)
+
+
 def test_layout_dim_major(matcher):
     a, b = synth.superpoint_pair(150, 170, 256, seed=7)
     s0 = matcher.upload_f32(np.ascontiguousarray(a.T), vsm.LAYOUT_DIM_MAJOR)
