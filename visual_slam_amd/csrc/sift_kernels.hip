@@ -672,7 +672,7 @@ void sift_select_tile_kernel(const SiftPair* __restrict__ pairs,
 }
 
 int sift_select_slices(int max_rows) { return std::max(1, std::min(kMaxRowSlices, (max_rows + 8191) / 8192)); }
-int sift_verify_rows_slices(int max_rows) { return std::max(1, std::min(kMaxRowSlices, (max_rows + 4095) / 4096)); }
+int sift_verify_rows_slices(int max_rows) { return sift_select_slices(max_rows); }   // 8192 rows: two rounds of a workgroup
 
 void launch_sift_select_tile(const SiftPair* pairs, int npairs, int max_rows, int max_chunks, int32_t* rr_y1,
                              int32_t* rr_tile, int32_t* rr_k2, MatchRule rule, SiftCandidates cand,
