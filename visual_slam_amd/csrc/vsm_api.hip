@@ -1202,10 +1202,10 @@ int f32_single_pair_fast(vsm_ctx* c, const DescSet* A, const DescSet* B, int set
     if (dense1) add(c->d_dense1.p, B->n, dense1);
     size_t words = 0;
     for (int k = 0; k < seg.n; ++k) words += (size_t)seg.count[k];
-    HIPCHK(c, c->d_stage.ensure(words * 4));
+    // the gather kernel writes straight into pinned host memory (it is mapped into the device's address space):
+    // no staging block and no copy command between the last kernel and the wait
     HIPCHK(c, c->h_gather.ensure(words * 4));
-    launch_gather_words(seg, c->d_stage.as<uint32_t>(), c->stream);
-    HIPCHK(c, hipMemcpyAsync(c->h_gather.p, c->d_stage.p, words * 4, hipMemcpyDeviceToHost, c->stream));
+    launch_gather_words(seg, c->h_gather.as<uint32_t>(), c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     const uint32_t* got = c->h_gather.as<uint32_t>();
@@ -1530,10 +1530,10 @@ extern "C" int vsm_match_pair(vsm_ctx* c, int set0, int set1, const vsm_params* 
     if (dist) add(c->d_slotd.p, take, dist);
     size_t words = 0;
     for (int k = 0; k < seg.n; ++k) words += (size_t)seg.count[k];
-    HIPCHK(c, c->d_stage.ensure(words * 4));
+    // the gather kernel writes straight into pinned host memory (it is mapped into the device's address space):
+    // no staging block and no copy command between the last kernel and the wait
     HIPCHK(c, c->h_gather.ensure(words * 4));
-    launch_gather_words(seg, c->d_stage.as<uint32_t>(), c->stream);
-    HIPCHK(c, hipMemcpyAsync(c->h_gather.p, c->d_stage.p, words * 4, hipMemcpyDeviceToHost, c->stream));
+    launch_gather_words(seg, c->h_gather.as<uint32_t>(), c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     const uint32_t* got = c->h_gather.as<uint32_t>();
