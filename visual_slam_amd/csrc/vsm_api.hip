@@ -107,7 +107,7 @@ struct vsm_ctx {
     std::string err;
     std::vector<DescSet> sets;
     // workspace (grow-only)
-    DevBuf d_pairs, d_items, d_rr1, d_rrj, d_rr2, d_colpart, d_cand;
+    DevBuf d_pairs, d_rr1, d_rrj, d_rr2, d_colpart, d_cand;
     DevBuf d_slot0, d_slot1, d_slotd, d_counts;
     DevBuf d_zero_tile;   // kTileBytes of zeros (see SiftCandidates::zero_tile)
     DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_probs, d_geom, d_short;
@@ -122,7 +122,7 @@ struct vsm_ctx {
     // submission k + 1 while the match lists of submission k travel to the host on copy_stream.
     struct ResultSlot {
         DevBuf d_offsets, d_tight0, d_tight1;
-        HostBuf h_pairs, h_items, h_off;
+        HostBuf h_pairs, h_off;
         hipEvent_t packed = nullptr;
         hipEvent_t staged = nullptr;    // the slot's pinned staging buffers have been copied to the device
         bool staged_recorded = false;
@@ -274,10 +274,11 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     const int nitems = (int)pl.items.size();
     c->R().query_pairs = npairs;
     const int nvitems = rule.mutual ? pl.max_vitems : 0;
-    HIPCHK(c, c->R().h_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
-    HIPCHK(c, c->R().h_items.ensure(sizeof(SiftItem) * std::max(nitems, 1)));
-    HIPCHK(c, c->d_pairs.ensure(sizeof(SiftPair) * std::max(npairs, 1)));
-    HIPCHK(c, c->d_items.ensure(sizeof(SiftItem) * std::max(nitems + nvitems, 1) + 64));
+    // pair records and work items share one pinned block and one device block, [pairs | items | the verify
+    // pass's items and their counter (written on the device)]: one copy command per submission
+    const size_t pairs_bytes = (sizeof(SiftPair) * std::max(npairs, 1) + 255) & ~(size_t)255;
+    HIPCHK(c, c->R().h_pairs.ensure(pairs_bytes + sizeof(SiftItem) * std::max(nitems, 1)));
+    HIPCHK(c, c->d_pairs.ensure(pairs_bytes + sizeof(SiftItem) * std::max(nitems + nvitems, 1) + 64));
     const size_t rows = std::max<size_t>(pl.rows, 1);
     const size_t out0 = std::max<size_t>(pl.out0, 1), out1 = std::max<size_t>(pl.out1, 1);
     HIPCHK(c, c->d_rr1.ensure(rows * 4));
@@ -323,11 +324,12 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     // that copy, not for the stream (a submission queued behind another one would otherwise leave the chip idle
     // between the two while the host catches up).
     if (c->R().staged_recorded) HIPCHK(c, hipEventSynchronize(c->R().staged));
+    SiftItem* const d_items = reinterpret_cast<SiftItem*>(c->d_pairs.as<char>() + pairs_bytes);
     if (npairs) memcpy(c->R().h_pairs.p, pl.pairs.data(), sizeof(SiftPair) * npairs);
-    if (nitems) memcpy(c->R().h_items.p, pl.items.data(), sizeof(SiftItem) * nitems);
-    if (npairs) HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->R().h_pairs.p, sizeof(SiftPair) * npairs, hipMemcpyHostToDevice, c->stream));
-    if (nitems)
-        HIPCHK(c, hipMemcpyAsync(c->d_items.p, c->R().h_items.p, sizeof(SiftItem) * nitems, hipMemcpyHostToDevice, c->stream));
+    if (nitems) memcpy(c->R().h_pairs.as<char>() + pairs_bytes, pl.items.data(), sizeof(SiftItem) * nitems);
+    if (npairs)
+        HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->R().h_pairs.p, nitems ? pairs_bytes + sizeof(SiftItem) * nitems : sizeof(SiftPair) * npairs,
+                                 hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->R().staged, c->stream));
     c->R().staged_recorded = true;
 
@@ -337,10 +339,10 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     if (nitems) {
         if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
         if (tile_path)
-            launch_sift_query_tile(c->d_pairs.as<SiftPair>(), c->d_items.as<SiftItem>(), nitems,
+            launch_sift_query_tile(c->d_pairs.as<SiftPair>(), d_items, nitems,
                                    c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), c->stream);
         else
-            launch_sift_query(c->d_pairs.as<SiftPair>(), c->d_items.as<SiftItem>(), nitems,
+            launch_sift_query(c->d_pairs.as<SiftPair>(), d_items, nitems,
                               c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(),
                               rule.num2 > 0 || o.want_knn, c->stream);
         if (c->timing) {
@@ -397,8 +399,8 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
         }
         if (nvitems) {
             if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev2, c->stream));
-            launch_sift_verify(c->d_pairs.as<SiftPair>(), npairs, c->d_items.as<SiftItem>() + nitems, nvitems,
-                               reinterpret_cast<int*>(c->d_items.as<SiftItem>() + nitems + nvitems), cand, c->stream);
+            launch_sift_verify(c->d_pairs.as<SiftPair>(), npairs, d_items + nitems, nvitems,
+                               reinterpret_cast<int*>(d_items + nitems + nvitems), cand, c->stream);
             if (c->timing) {
                 HIPCHK(c, hipEventRecord(c->R().ev3, c->stream));
                 c->R().ev_verify_valid = true;
@@ -512,7 +514,7 @@ extern "C" void vsm_destroy(vsm_ctx* c)
         if (s.nrm) (void)hipFree(s.nrm);
         if (s.shadow) (void)hipFree(s.shadow);
     }
-    DevBuf* bufs[] = {&c->d_zero_tile, &c->d_pairs, &c->d_items, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart, &c->d_cand,
+    DevBuf* bufs[] = {&c->d_zero_tile, &c->d_pairs, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart, &c->d_cand,
                       &c->d_slot0, &c->d_slot1, &c->d_slotd, &c->d_counts, &c->d_dense0, &c->d_dense1,
                       &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage, &c->d_coarse,
                       &c->d_probs, &c->d_geom, &c->d_short};
@@ -522,7 +524,6 @@ extern "C" void vsm_destroy(vsm_ctx* c)
         r.d_tight0.release();
         r.d_tight1.release();
         r.h_pairs.release();
-        r.h_items.release();
         r.h_off.release();
         if (r.packed) (void)hipEventDestroy(r.packed);
         if (r.staged) (void)hipEventDestroy(r.staged);
