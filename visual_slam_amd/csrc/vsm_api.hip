@@ -1953,10 +1953,15 @@ extern "C" int vsm_knn2_device(vsm_ctx* c, int set_q, int set_db, int metric, vo
     }
     F32Result r;
     if ((rc = run_f32_knn(c, A, B, metric, false, &r)) != VSM_OK) return rc;
-    HIPCHK(c, hipMemcpyAsync(out, r.k1, nq * 4, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(out + nq, r.k2, nq * 4, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(out + 2 * nq, r.j1, nq * 4, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(out + 3 * nq, r.j2, nq * 4, hipMemcpyDeviceToDevice, c->stream));
+    // the four arrays side by side in the caller's buffer: one kernel instead of four copy commands
+    WordSegments seg{};
+    const void* src[4] = {r.k1, r.k2, r.j1, r.j2};
+    for (int k = 0; k < 4; ++k) {
+        seg.src[k] = static_cast<const uint32_t*>(src[k]);
+        seg.count[k] = (int)nq;
+    }
+    seg.n = 4;
+    launch_gather_words(seg, reinterpret_cast<uint32_t*>(out), c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return A->n;
 }
