@@ -10,6 +10,8 @@ in this container (never on the GPU box; /root/reference does not travel).
   - matching_ref.txt       get_list_matching_pairs + save_matching_sfm (main.py:114-155), executed
   - pairs_ref.txt          generate_imagePairs (main.py:157-169), executed
   - feature_ref.txt        save_feature_locations (main.py:133-140), executed
+  - resort_ref.npz         sort_scores, sort_feature_Or_descriptors, get_correct_new_matching_index
+                           (main.py:75-112) executed in the order of the exporter's loop (main.py:253-266)
 main.py cannot be imported (it needs cv2 and runs its whole pipeline at import), so its pure helper
 functions are compiled from its source text with ast and executed here.
 
@@ -30,7 +32,8 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 def load_main_helpers():
     path = os.path.join(REF, "Others/SuperPoint_data/main.py")
     tree = ast.parse(open(path).read())
-    wanted = {"get_list_matching_pairs", "save_matching_sfm", "generate_imagePairs", "save_feature_locations"}
+    wanted = {"get_list_matching_pairs", "save_matching_sfm", "generate_imagePairs", "save_feature_locations",
+              "sort_scores", "sort_feature_Or_descriptors", "get_correct_new_matching_index"}
     body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in wanted]
     # module-level constants the helpers' default arguments refer to (main.py:35-36)
     consts = [n for n in tree.body if isinstance(n, ast.Assign) and
@@ -162,9 +165,41 @@ def gen_text_formats():
     h["save_feature_locations"](kp, os.path.join(OUT, "feature_ref.txt"))
 
 
+def gen_resort():
+    """The exporter's re-sort of one pair (main.py:253-266): keypoints of both images ordered by descending
+    detector score, the dense match array carried along and re-indexed.  Scores hold ties."""
+    h = load_main_helpers()
+    rng = np.random.default_rng(11)
+    n0, n1 = 57, 43
+    scores0 = np.round(rng.random(n0), 2).astype(np.float32)     # two decimals: ties
+    scores1 = np.round(rng.random(n1), 2).astype(np.float32)
+    kpts0 = (rng.random((n0, 2)) * np.array([640, 480])).astype(np.float32)
+    kpts1 = (rng.random((n1, 2)) * np.array([640, 480])).astype(np.float32)
+    matches = -np.ones(n0, np.int64)
+    pick = rng.choice(n0, 20, replace=False)
+    matches[pick] = rng.choice(n1, 20, replace=False)
+    conf = rng.random(n0).astype(np.float32)
+    n_scores0, idx0 = h["sort_scores"](scores0)
+    n_kpts0 = h["sort_feature_Or_descriptors"](kpts0, idx0)
+    n_scores1, idx1 = h["sort_scores"](scores1)
+    n_kpts1 = h["sort_feature_Or_descriptors"](kpts1, idx1)
+    n_matches = h["sort_feature_Or_descriptors"](matches, idx0)
+    n_conf = h["sort_feature_Or_descriptors"](conf, idx0)
+    n_matches = h["get_correct_new_matching_index"](n_matches, idx1)
+    np.savez(os.path.join(OUT, "resort_ref.npz"), scores0=scores0, scores1=scores1, kpts0=kpts0, kpts1=kpts1,
+             matches=matches, conf=conf, n_scores0=n_scores0, idx0=idx0, n_kpts0=n_kpts0, n_scores1=n_scores1,
+             idx1=idx1, n_kpts1=n_kpts1, n_matches=n_matches, n_conf=n_conf)
+
+
 if __name__ == "__main__":
-    gen_nearest_embed()
-    gen_nearest_embed_near_ties()
-    gen_mutual_block()
-    gen_text_formats()
+    which = set(sys.argv[1:])
+    if not which or "nearest_embed" in which:
+        gen_nearest_embed()
+        gen_nearest_embed_near_ties()
+    if not which or "mutual_block" in which:
+        gen_mutual_block()
+    if not which or "text" in which:
+        gen_text_formats()
+    if not which or "resort" in which:
+        gen_resort()
     print("fixtures written to", OUT)

@@ -313,3 +313,30 @@ def test_mat_writer_leaves_the_same_bytes_as_repeated_calls(tmp_path):
     ga, gb = host.get_pmatch(str(d2 / ("im%d" % a)), str(d2 / ("im%d" % b)), fc[b])
     np.testing.assert_array_equal(ga, i0)
     np.testing.assert_array_equal(gb, i1)
+
+
+def test_resort_by_score_fixture():
+    """sort_scores / sort_feature_Or_descriptors / get_correct_new_matching_index against the outputs of the
+    reference's own functions (main.py:75-112, executed by tests/golden/gen_golden.py on scores with ties)."""
+    z = np.load(os.path.join(G, "resort_ref.npz"))
+    s0, i0 = host.sort_scores(z["scores0"])
+    s1, i1 = host.sort_scores(z["scores1"])
+    np.testing.assert_array_equal(s0, z["n_scores0"])
+    np.testing.assert_array_equal(i0, z["idx0"])
+    np.testing.assert_array_equal(s1, z["n_scores1"])
+    np.testing.assert_array_equal(i1, z["idx1"])
+    for got, want in ((host.sort_feature_Or_descriptors(z["kpts0"], i0), z["n_kpts0"]),
+                      (host.sort_feature_Or_descriptors(z["kpts1"], i1), z["n_kpts1"]),
+                      (host.sort_feature_Or_descriptors(z["conf"], i0), z["n_conf"])):
+        assert got.dtype == want.dtype
+        np.testing.assert_array_equal(got, want)
+    nm = host.get_correct_new_matching_index(host.sort_feature_Or_descriptors(z["matches"], i0), i1)
+    assert nm.dtype == z["n_matches"].dtype
+    np.testing.assert_array_equal(nm, z["n_matches"])
+    k0, k1, nm2 = host.resort_pair_by_score(z["kpts0"], z["scores0"], z["kpts1"], z["scores1"], z["matches"])
+    np.testing.assert_array_equal(k0, z["n_kpts0"])
+    np.testing.assert_array_equal(k1, z["n_kpts1"])
+    np.testing.assert_array_equal(nm2, z["n_matches"])
+    # and the list the exporter writes from it
+    l0, l1, n = host.get_list_matching_pairs(nm2)
+    assert n == 20 and len(l0.split()) == 20 and len(l1.split()) == 20

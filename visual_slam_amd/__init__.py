@@ -27,6 +27,10 @@ from ._binding import (  # noqa: F401
 from .host import (  # noqa: F401
     generate_imagePairs,
     generate_exhaustive_pairs,
+    sort_scores,
+    sort_feature_Or_descriptors,
+    get_correct_new_matching_index,
+    resort_pair_by_score,
     get_list_matching_pairs,
     save_matching_sfm,
     save_feature_locations,
@@ -53,6 +57,7 @@ __all__ = [
     "METRIC_DOT", "METRIC_L2", "LAYOUT_ROWS", "LAYOUT_DIM_MAJOR", "NO_SECOND",
     "F32_FAST_EXACT", "F32_MFMA_F32", "F32_REVERSE_AUTO", "F32_REVERSE_CANDIDATES", "F32_REVERSE_ALL", "U8_AUTO", "U8_PACKED",
     "generate_imagePairs", "generate_exhaustive_pairs", "get_list_matching_pairs",
+    "sort_scores", "sort_feature_Or_descriptors", "get_correct_new_matching_index", "resort_pair_by_score",
     "save_matching_sfm", "save_feature_locations", "read_feature_locations",
     "read_sift", "write_sift", "write_pmatch", "get_pmatch", "get_pmatch_r", "get_match_count",
     "write_fmatch", "write_ematch", "get_pose", "estimate_pose", "get_imatch", "get_imatch_r", "estimate_fundamental",

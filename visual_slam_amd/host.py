@@ -41,6 +41,48 @@ def generate_exhaustive_pairs(n):
     return out[:cnt]
 
 
+# ---- re-sort of a pair by detector score (main.py:75-112, used at main.py:253-266) --------------
+def sort_scores(scores):
+    """Scores in descending order and the original index of each (main.py:75-83): the flipped ascending
+    sort, so equal scores come out in the reverse of numpy's argsort order, as in the reference."""
+    scores = np.asarray(scores)
+    return np.flip(np.sort(scores)), np.flip(np.argsort(scores))
+
+
+def sort_feature_Or_descriptors(data, sorted_index):
+    """Rows (or entries of a 1-D array) of `data` in the order of `sorted_index`, as float64 like the
+    reference's zero-filled result (main.py:85-102); one gather instead of a Python loop."""
+    data = np.asarray(data)
+    sorted_index = np.asarray(sorted_index)
+    if len(data) != len(sorted_index):
+        raise AssertionError("data and sorted_index differ in length")
+    return data[sorted_index].astype(np.float64)
+
+
+def get_correct_new_matching_index(old_match0, new_index1):
+    """Dense matches (-1 = none) that name image-1 keypoints by their OLD index, re-expressed in the new order
+    `new_index1` (new position p holds old keypoint new_index1[p]) (main.py:104-112).  The reference searches
+    new_index1 once per match; this inverts the permutation once."""
+    old = np.asarray(old_match0)
+    new_index1 = np.asarray(new_index1).astype(np.int64)
+    inv = np.empty(len(new_index1), np.int64)
+    inv[new_index1] = np.arange(len(new_index1))
+    out = -np.ones(len(old))
+    has = old != -1
+    out[has] = inv[old[has].astype(np.int64)]
+    return out
+
+
+def resort_pair_by_score(kpts0, scores0, kpts1, scores1, matches0):
+    """The exporter's re-sort of one pair (main.py:253-266): both images' keypoints by descending score and
+    the dense matches of image 0 carried along and re-indexed.  Returns (n_kpts0, n_kpts1, n_matches)."""
+    _, i0 = sort_scores(scores0)
+    _, i1 = sort_scores(scores1)
+    n_matches = sort_feature_Or_descriptors(matches0, i0)
+    return (sort_feature_Or_descriptors(kpts0, i0), sort_feature_Or_descriptors(kpts1, i1),
+            get_correct_new_matching_index(n_matches, i1))
+
+
 # ---- match txt (main.py:114-155) -------------------------------------------------------------
 def get_list_matching_pairs(matches):
     """Dense matches (-1 = none) -> (list_0, list_1, number_match) strings as the reference builds them."""
