@@ -338,8 +338,10 @@ void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
 //   * the accumulators start from the train rows' constants cq and the query operand is ~p, so the MFMA
 //     result is the half-distance y = floor(nrm(q) / 2) - p.q itself (no per-element arithmetic);
 //   * per lane and 32-row tile only the minimum m of the lane's 8 values of a query row is taken (four
-//     v_min / v_min3), then k2 = med3(k1, k2, m), tile = m < k1 ? this tile : tile, k1 = min(k1, m).
-// A lane therefore knows the smallest y of its query row (k1), the first tile that holds it, and the
+//     v_min / v_min3) and packed with the tile's number within the chunk, key = m * 256 + tile (one
+//     v_lshl_add), then k2 = med3(k1, k2, key), k1 = min(k1, key): among equal minima the first tile wins, and
+//     k2 >> 8 is the second smallest of the minima whatever tile it came from.
+// A lane therefore knows the smallest y of its query row (k1 >> 8), the first tile that holds it (k1 & 255), and the
 // second smallest of the per-(tile, lane quarter) minima (k2): an upper bound of the runner-up that misses only
 // rows of the winner's own 8-row group.  What this leaves open -- which row of the tile, the parity bit
 // that y drops, a runner-up inside the winner's group -- is settled for the candidates only, from that one
@@ -384,9 +386,11 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
     const int8_t* Bsrc = pw.fragB + (size_t)(c0 >> 5) * kTileBytes + wave * (kLdsTile / kQueryWaves) + lane * 16;
     const int32_t* Csrc = pw.nrmB + pw.nB_pad + c0 + (wave & 3) * 64 + lane;
 
-    int k1[kCB], k2[kCB], kt[kCB];
+    static_assert(kChunkCols / 32 <= 256, "the tile within a chunk must fit the low byte of a key");
+    constexpr int kKeyPad = kYPad * 256;
+    int k1[kCB], k2[kCB];   // packed keys: y * 256 + tile within the chunk
 #pragma unroll
-    for (int cb = 0; cb < kCB; ++cb) { k1[cb] = kYPad; k2[cb] = kYPad; kt[cb] = 0; }
+    for (int cb = 0; cb < kCB; ++cb) { k1[cb] = kKeyPad; k2[cb] = kKeyPad; }
 
     // Software pipeline in program order, pinned by scheduling barriers (nothing moves across one):
     //   * column blocks go in pairs: eight MFMAs (first k-step of both row blocks of both column blocks, then
@@ -412,14 +416,14 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
                 asm volatile("" : "+v"(mm[u]));
             }
         } else {
-            // one column block per piece, four instructions whose order is the compiler's (the compare and the
-            // select that reads its mask want other instructions between them)
+            // one column block per piece: three instructions
             const int u = stage - 2, cb = cb0 + u;
-            const int m = mm[u], b1 = k1[cb];
-            k2[cb] = max(min(b1, k2[cb]), min(max(b1, k2[cb]), m));   // v_med3_i32: the runner-up of {k1, k2, m}
-            kt[cb] = m < b1 ? tileno : kt[cb];                          // strict: the first tile that holds the minimum
-            k1[cb] = min(b1, m);
-            asm volatile("" : "+v"(k2[cb]), "+v"(kt[cb]), "+v"(k1[cb]));
+            int tn = tileno;
+            asm volatile("" : "+s"(tn));   // one scalar register: the packing is then a single v_lshl_add_u32
+            const int key = mm[u] * 256 + tn, b1 = k1[cb];
+            k2[cb] = max(min(b1, k2[cb]), min(max(b1, k2[cb]), key));   // v_med3_i32: the runner-up of {k1, k2, key}
+            k1[cb] = min(b1, key);                                       // equal minima: the lower tile number stays
+            asm volatile("" : "+v"(k2[cb]), "+v"(k1[cb]));
         }
     };
 
@@ -443,7 +447,7 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
             stage_step<kQueryWaves>(smem, cur ^ 1, Bsrc + (size_t)(st + 1) * kLdsTile, Csrc + (st + 1) * kStepRows, wave);
         const char* Bt = smem + cur * kLdsTile + lane_off;
         const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm) + quad * 4;
-        const int tile0 = (c0 >> 5) + st * kTilesPerStep;
+        const int tile0 = st * kTilesPerStep;   // tile numbers count from the chunk's first tile
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < kTilesPerStep; ++t) {
@@ -500,7 +504,7 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
     for (int cb = 0; cb < kCB; ++cb) {
         // the four lane quarters saw disjoint 8-row groups of every tile for the same query row; what goes on to
         // the resolve pass is the winner's GROUP: tile * 4 + lane quarter (rows 4 q .. 4 q + 3 of both row blocks)
-        int y1 = k1[cb], y2 = k2[cb], tl = kt[cb] * 4 + quad;
+        int y1 = k1[cb] >> 8, y2 = k2[cb] >> 8, tl = ((c0 >> 5) + (k1[cb] & 255)) * 4 + quad;
 #pragma unroll
         for (int d = 16; d <= 32; d <<= 1) {
             const int o1 = __shfl_xor(y1, d);

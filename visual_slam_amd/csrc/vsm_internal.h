@@ -32,11 +32,13 @@ constexpr int32_t kNormPad = 0x7FFFFF00;
 constexpr int32_t kDistPad = 0x7FFFFF;  // (kNormPad >> 8): "no such neighbour"
 // Half-distance domain of the tile-minimum query pass: for a query row p and a train row q (both int8),
 //     y = floor(nrm(q) / 2) - dot(p, q),   nrm(q) - 2 dot(p, q) = 2 y + (nrm(q) & 1),
-// |y| < 2^22 for real rows; padding rows and "no such neighbour" are kYPad.
+// -2^21 <= y <= 2^21 + 2^20 for real rows; padding rows (zero operand bytes, so their accumulators end where they
+// start) and "no such neighbour" are kYPad = 2^22, small enough for y * 256 + (tile within the chunk) to fit an int32:
+// the query pass ranks such packed keys.
 // The int32 array of a u8 set holds nrm8c[n_pad] followed by these constants, cq[n_pad]:
 //     cq[row] = floor(nrm / 2) + (sum of the row's int8 values)
 // (the query operand enters the MFMA as ~p = -p - 1, so the accumulator that starts at cq ends at y).
-constexpr int32_t kYPad = 1 << 28;
+constexpr int32_t kYPad = 1 << 22;
 
 struct SiftPair {
     const int8_t* fragA;     // image 0 (queries)
