@@ -87,6 +87,24 @@ def test_extreme_values(matcher):
     _check_pair(matcher, a, b)
 
 
+def test_extreme_values_over_a_whole_chunk(matcher):
+    """The query pass ranks half-distance * 256 + (tile within the chunk): the largest and the smallest
+    half-distance there is, in every one of the 256 tiles of an 8192-row chunk, with the nearest row of some
+    queries in the last tile."""
+    rng = np.random.default_rng(18)
+    b = np.full((8192, 128), 255, np.uint8)
+    b[1::2] = 0
+    b[8190] = rng.integers(0, 256, 128, dtype=np.uint8)
+    a = np.zeros((96, 128), np.uint8)          # all-0 queries: distance 0 to the odd rows, the maximum to the even ones
+    a[32:64] = 255                             # all-255 queries: the other way round
+    a[64:] = rng.integers(0, 256, (32, 128), dtype=np.uint8)
+    a[70] = b[8190]                            # nearest row in the last tile
+    a[71] = np.clip(b[8190].astype(np.int32) + rng.integers(-2, 3, 128), 0, 255).astype(np.uint8)
+    _check_pair(matcher, a, b)
+    _check_pair(matcher, a, b, ratio=None)
+    _check_pair(matcher, b[:700], a)
+
+
 def test_uniform_random_bytes(matcher):
     rng = np.random.default_rng(9)
     a = rng.integers(0, 256, (513, 128), dtype=np.uint8)
