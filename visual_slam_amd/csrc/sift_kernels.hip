@@ -332,6 +332,29 @@ void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
     }
 }
 
+__device__ __forceinline__ int dot16(const v4i a, const v4i b, int acc)
+{
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc = __builtin_amdgcn_sdot4(a[w], b[w], acc, false);
+    return acc;
+}
+
+
+__device__ __forceinline__ bool ratio_ok(const MatchRule& rule, long long d1, long long d2)
+{
+    return rule.num2 <= 0 || d1 * rule.den2 < d2 * rule.num2;
+}
+
+// minimum over each group of 8 lanes, valid in all 8 (three DPP steps, no LDS round trip)
+__device__ __forceinline__ int group8_min(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));   // row_half_mirror: lane k <-> 7 - k
+    return v;
+}
+
+
 // ---- 1b. query pass, tile-minimum form ---------------------------------------------------
 // The form above spends 2.25 vector instructions per distance (scale + pack, running two smallest), which
 // makes the vector issue port, not the matrix pipe, its limit.  This form spends 1.0:
@@ -353,10 +376,12 @@ void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
 // of 16, K = 128 two steps of 64 (lane quarter q = l >> 4 holds k = 64 c + 16 q .. + 15 of both operands,
 // and accumulator registers 0..3 hold rows 4 q .. 4 q + 3 of the row block).  Operands are read out of the
 // same fragment-major arrays: bytes k = 32 s + 16 h .. + 15 of row r of a tile lie at s * 1024 + (h * 32 + r) * 16.
+template <bool FUSED>
 __global__ __launch_bounds__(kQueryWaves * 64, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __restrict__ items,
                               int32_t* __restrict__ rr_y1, int32_t* __restrict__ rr_tile,
-                              int32_t* __restrict__ rr_k2)
+                              int32_t* __restrict__ rr_k2, MatchRule rule, SiftCandidates cand,
+                              int32_t* __restrict__ seg_counts)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SiftItem it = items[xcd_contiguous_item(blockIdx.x, gridDim.x)];
@@ -500,6 +525,13 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
 #pragma unroll
     for (int stage = 0; stage < 4; ++stage) epi(stage, 6, pend_tile);
 
+    // FUSED (pairs whose train set is one chunk): the select and resolve passes of this strip's 512 rows run here,
+    // while the train image the strip has just streamed is still in the XCD's L2.  Candidates go to the strip's own
+    // segment of the pair's candidate arrays (out0_off + strip * 512 + k, ascending rows); a gather pass closes the
+    // gaps between the segments afterwards.
+    int4* s_cand = reinterpret_cast<int4*>(smem);                       // [4 waves][128]: (row, group, y1, y2)
+    int* s_cnt = reinterpret_cast<int*>(smem + 4 * 128 * sizeof(int4));  // [4]
+    int wcount = 0;
 #pragma unroll
     for (int cb = 0; cb < kCB; ++cb) {
         // the four lane quarters saw disjoint 8-row groups of every tile for the same query row; what goes on to
@@ -515,23 +547,149 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
             tl = other ? ot : tl;
             y1 = min(y1, o1);
         }
+        const int grow = qtile * 32 + cb * 16 + l16;
         if (quad == 0) {
-            const int grow = qtile * 32 + cb * 16 + l16;
             const size_t o = pw.row_off + (size_t)it.chunk * pw.nA_pad + grow;
             rr_y1[o] = y1;
-            rr_tile[o] = tl;
-            rr_k2[o] = y2;
+            if (!FUSED) {
+                rr_tile[o] = tl;
+                rr_k2[o] = y2;
+            }
+        }
+        if (FUSED) {
+            // the select pass's optimistic tests (d1 at its lowest, d2 at its highest)
+            bool ok = quad == 0 && grow < pw.nA && y1 < kYPad;
+            if (ok) {
+                const long long na = pw.nrmA[grow] >> 8;
+                const long long d1lo = 2ll * y1 + na;
+                if (rule.max_dist >= 0 && d1lo > rule.max_dist) ok = false;
+                if (ok && rule.num2 > 0 && y2 < kYPad) {
+                    const long long d2hi = 2ll * y2 + 1 + na;
+                    if (!(d1lo * rule.den2 < d2hi * rule.num2)) ok = false;
+                }
+            }
+            const unsigned long long mask = __ballot(ok);
+            if (ok) s_cand[wave * 128 + wcount + __popcll(mask & ((1ull << lane) - 1ull))] = make_int4(grow, tl, y1, y2);
+            wcount += __popcll(mask);
         }
     }
+    if (FUSED) {
+        if (lane == 0) s_cnt[wave] = wcount;
+        __syncthreads();
+        int pre[kQueryWaves + 1];
+        pre[0] = 0;
+#pragma unroll
+        for (int v = 0; v < kQueryWaves; ++v) pre[v + 1] = pre[v] + s_cnt[v];
+        const int total = pre[kQueryWaves];
+        const int k8 = lane & 7, grp = lane >> 3;
+        const int8_t VSM_GLB* fragA = (const int8_t VSM_GLB*)pw.fragA;
+        const int8_t VSM_GLB* fragB = (const int8_t VSM_GLB*)pw.fragB;
+        const int32_t VSM_GLB* nrmB = (const int32_t VSM_GLB*)pw.nrmB;
+        const int seg0 = it.strip * kStripRows;
+        for (int c0c = wave * 8; c0c < total; c0c += kQueryWaves * 8) {
+            const int c = c0c + grp;
+            const bool have = c < total;
+            const int cc = have ? c : c0c;
+            int v = 0;
+#pragma unroll
+            for (int u = 1; u < kQueryWaves; ++u) v += cc >= pre[u] ? 1 : 0;
+            const int4 rec = s_cand[v * 128 + (cc - pre[v])];
+            const int i = rec.x, g = rec.y, y1 = rec.z, y2 = rec.w;
+            const long long na = pw.nrmA[i] >> 8;
+            const int tl = g >> 2, qd = g & 3;
+            const int r = (k8 >> 2) * 16 + qd * 4 + (k8 & 3);     // row of the tile
+            const int8_t VSM_GLB* q = fragA + (size_t)(i >> 5) * kTileBytes + (i & 31) * 16;
+            const int8_t VSM_GLB* t = fragB + (size_t)tl * kTileBytes + r * 16;
+            int dot = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    dot = dot16(*reinterpret_cast<const v4i VSM_GLB*>(q + s * 1024 + h * 512),
+                                *reinterpret_cast<const v4i VSM_GLB*>(t + s * 1024 + h * 512), dot);
+            }
+            const int row = tl * 32 + r;
+            const int key = row < pw.nB ? ((nrmB[row] >> 8) - 2 * dot) * 8 + k8 : INT32_MAX;
+            const int best = group8_min(key);
+            const int second = group8_min(k8 == (best & 7) ? INT32_MAX : key);
+            const int kb = best & 7, x1 = best >> 3;
+            const long long d1 = (long long)x1 + na;
+            bool amb = y2 == y1 || (x1 >> 1) != y1;
+            bool pass = false;
+            if (!amb) {
+                const bool has_in = second != INT32_MAX, has_out = y2 < kYPad;
+                bool pr = true;
+                if (has_in || has_out) {
+                    const long long in_x = has_in ? (long long)(second >> 3) : INT64_MAX / 4;
+                    const long long out_lo = has_out ? 2ll * y2 : INT64_MAX / 4;
+                    const bool pa = ratio_ok(rule, d1, min(in_x, out_lo) + na);
+                    const bool pb = ratio_ok(rule, d1, min(in_x, out_lo + 1) + na);
+                    if (pa != pb) amb = true;
+                    pr = pa;
+                }
+                pass = pr && (rule.max_dist < 0 || d1 <= rule.max_dist);
+            }
+            if (have && k8 == 0) {
+                const int cpos = seg0 + c;
+                const size_t o = pw.out0_off + cpos;
+                cand.i0[o] = i;
+                cand.vbest[o] = ~0ull;
+                if (amb) {
+                    const int e = atomicAdd(cand.rescan_count, 1);
+                    cand.rescan_list[e] = make_int2(it.pair, cpos);
+                    cand.j1[o] = -1;
+                    cand.d1[o] = 0;
+                } else {
+                    cand.j1[o] = pass ? tl * 32 + (kb >> 2) * 16 + qd * 4 + (kb & 3) : -1;
+                    cand.d1[o] = (int)d1;
+                    if (pass) atomicMax(&cand.dmax[it.pair], (int)d1);
+                }
+            }
+        }
+        if (tid == 0) seg_counts[it.pair * (kChunkCols / kStripRows) + it.strip] = total;
+    }
+}
+
+// Closes the gaps between the strips' candidate segments of the fused query pass: one workgroup per pair moves the
+// segments to the front in strip order (a segment only ever moves towards lower positions, and the segments before it
+// have moved already) and leaves the pair's candidate count.
+__global__ __launch_bounds__(kStripRows)
+void sift_gather_segments_kernel(const SiftPair* __restrict__ pairs, const int32_t* __restrict__ seg_counts,
+                                 SiftCandidates cand)
+{
+    const SiftPair pw = pairs[blockIdx.x];
+    const int tid = threadIdx.x;
+    int base = 0;
+    for (int sidx = 0; sidx < pw.nstrips; ++sidx) {
+        const int n = seg_counts[blockIdx.x * (kChunkCols / kStripRows) + sidx];
+        const size_t src = pw.out0_off + (size_t)sidx * kStripRows + tid;
+        int i = 0, j = 0, d = 0;
+        if (tid < n) {
+            i = cand.i0[src];
+            j = cand.j1[src];
+            d = cand.d1[src];
+        }
+        __syncthreads();
+        if (tid < n) {
+            const size_t dst = pw.out0_off + base + tid;
+            cand.i0[dst] = i;
+            cand.j1[dst] = j;
+            cand.d1[dst] = d;
+            cand.vbest[dst] = ~0ull;
+        }
+        __syncthreads();
+        base += n;
+    }
+    if (tid == 0) cand.count[blockIdx.x] = base;
 }
 
 void launch_sift_query_tile(const SiftPair* pairs, const SiftItem* items, int nitems,
                             int32_t* rr_y1, int32_t* rr_tile, int32_t* rr_k2, hipStream_t s)
 {
     static DeviceFlags attr_set;   // the attribute is per device
-    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(sift_query_tile_kernel), kLdsStream);
-    hipLaunchKernelGGL(sift_query_tile_kernel, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
-                       pairs, items, rr_y1, rr_tile, rr_k2);
+    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(sift_query_tile_kernel<false>), kLdsStream);
+    hipLaunchKernelGGL(sift_query_tile_kernel<false>, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
+                       pairs, items, rr_y1, rr_tile, rr_k2, MatchRule{}, SiftCandidates{}, nullptr);
 }
 
 // ---- 2b. select, tile-minimum form --------------------------------------------------------
@@ -697,13 +855,6 @@ void launch_sift_select_tile(const SiftPair* pairs, int npairs, int max_rows, in
 }
 
 // ---- 2c. resolve / rescan ------------------------------------------------------------------
-__device__ __forceinline__ int dot16(const v4i a, const v4i b, int acc)
-{
-#pragma unroll
-    for (int w = 0; w < 4; ++w) acc = __builtin_amdgcn_sdot4(a[w], b[w], acc, false);
-    return acc;
-}
-
 // nrm(q) - 2 p.q for row (lane & 31) of 32-row train tile `tile` (INT32_MAX for padding rows), the same
 // value in lanes l and l + 32.  qa: this lane's 16-byte pieces of the query row, one per k-step.
 __device__ __forceinline__ int tile_row_x(const SiftPair& pw, int tile, int lane, const v4i (&qa)[4])
@@ -721,20 +872,6 @@ __device__ __forceinline__ int wave_min32(int v)   // minimum over lanes 0..31, 
 {
 #pragma unroll
     for (int d = 16; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
-    return v;
-}
-
-__device__ __forceinline__ bool ratio_ok(const MatchRule& rule, long long d1, long long d2)
-{
-    return rule.num2 <= 0 || d1 * rule.den2 < d2 * rule.num2;
-}
-
-// minimum over each group of 8 lanes, valid in all 8 (three DPP steps, no LDS round trip)
-__device__ __forceinline__ int group8_min(int v)
-{
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));   // row_half_mirror: lane k <-> 7 - k
     return v;
 }
 
@@ -871,6 +1008,28 @@ void sift_rescan_kernel(const SiftPair* __restrict__ pairs, MatchRule rule, Sift
             if (pass) atomicMax(&cand.dmax[pc.x], (int)d1);
         }
     }
+}
+
+// The query pass with the select and resolve passes of every strip in its tail (every pair's sets must be one chunk
+// of rows at most); cand.rescan_count and cand.dmax are initialised here.  launch_sift_fused_finish follows it: the
+// rescan pass over what the tails could not settle, and the gather pass over their segments.
+void launch_sift_query_tile_fused(const SiftPair* pairs, int npairs, const SiftItem* items, int nitems,
+                                  int32_t* rr_y1, MatchRule rule, SiftCandidates cand, int32_t* seg_counts,
+                                  hipStream_t s)
+{
+    static DeviceFlags attr_set;
+    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(sift_query_tile_kernel<true>), kLdsStream);
+    (void)hipMemsetAsync(cand.rescan_count, 0, sizeof(int32_t), s);
+    (void)hipMemsetAsync(cand.dmax, 0x80, sizeof(int32_t) * npairs, s);   // below every distance
+    hipLaunchKernelGGL(sift_query_tile_kernel<true>, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
+                       pairs, items, rr_y1, nullptr, nullptr, rule, cand, seg_counts);
+}
+
+void launch_sift_fused_finish(const SiftPair* pairs, int npairs, MatchRule rule, SiftCandidates cand,
+                              const int32_t* seg_counts, hipStream_t s)
+{
+    hipLaunchKernelGGL(sift_rescan_kernel, dim3(kRescanGrid), dim3(kResolveWaves * 64), 0, s, pairs, rule, cand);
+    hipLaunchKernelGGL(sift_gather_segments_kernel, dim3(npairs), dim3(kStripRows), 0, s, pairs, seg_counts, cand);
 }
 
 // The image-0 rows that can matter to the mutual check of a pair (see SiftCandidates::dmax), in ascending order.

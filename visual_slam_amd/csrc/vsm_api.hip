@@ -292,7 +292,8 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
         max_rows = std::max(max_rows, sp.nA);
         max_chunks = std::max(max_chunks, sp.nchunks);
     }
-    const int slice_ints = std::max(sift_select_slices(max_rows), sift_verify_rows_slices(max_rows));
+    const int slice_ints = std::max(std::max(sift_select_slices(max_rows), sift_verify_rows_slices(max_rows)),
+                                    kChunkCols / kStripRows);
     HIPCHK(c, c->d_cand.ensure(out0 * 40 + sizeof(int32_t) * ((3 + (size_t)slice_ints) * std::max(npairs, 1) + 16)));
     if (!c->d_zero_tile.p) {
         HIPCHK(c, c->d_zero_tile.ensure(kTileBytes));
@@ -301,6 +302,10 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     // The tile-minimum query pass leaves row and exact distances to a resolve pass over the candidates: it
     // pays when the ratio test keeps the candidates few, and it does not produce the raw 2-NN outputs.
     const bool tile_path = c->u8_mode == 0 && !o.packed_only && rule.num2 > 0 && !o.want_knn;
+    // select and resolve passes in the tail of the query pass: every pair at most one chunk of rows on either side
+    // (a call with a pair or two is bound by its launches, and this form has one more of them)
+    bool fused = tile_path && nitems > 0 && npairs >= 8 && getenv("VSM_NO_FUSED") == nullptr;
+    for (const SiftPair& sp : pl.pairs) fused = fused && sp.nchunks <= 1 && sp.nstrips <= kChunkCols / kStripRows;
     c->last_u8_path = nitems ? (tile_path ? 0 : 1) : c->last_u8_path;
     HIPCHK(c, c->d_slot0.ensure(out0 * 4));
     HIPCHK(c, c->d_slot1.ensure(out0 * 4));
@@ -337,15 +342,17 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     c->timing_slot = c->rs;
     c->R().ev_verify_valid = false;
     if (nitems) {
-        if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
-        if (tile_path)
+        if (c->timing && !fused) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
+        if (fused) {
+            // launched below, once the candidate arrays are laid out
+        } else if (tile_path)
             launch_sift_query_tile(c->d_pairs.as<SiftPair>(), d_items, nitems,
                                    c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), c->stream);
         else
             launch_sift_query(c->d_pairs.as<SiftPair>(), d_items, nitems,
                               c->d_rr1.as<int32_t>(), c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(),
                               rule.num2 > 0 || o.want_knn, c->stream);
-        if (c->timing) {
+        if (c->timing && !fused) {
             HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
             c->R().ev_valid = true;
         }
@@ -386,7 +393,19 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
             out.knn_d1 = c->d_knn1.as<int32_t>();
             out.knn_d2 = c->d_knn2.as<int32_t>();
         }
-        if (tile_path) {
+        if (fused) {
+            if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
+            launch_sift_query_tile_fused(c->d_pairs.as<SiftPair>(), npairs, d_items, nitems, c->d_rr1.as<int32_t>(), rule,
+                                         cand, slice_counts, c->stream);
+            if (c->timing) {
+                HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
+                c->R().ev_valid = true;
+            }
+            launch_sift_fused_finish(c->d_pairs.as<SiftPair>(), npairs, rule, cand, slice_counts, c->stream);
+            if (nvitems)
+                launch_sift_verify_rows(c->d_pairs.as<SiftPair>(), npairs, max_rows, c->d_rr1.as<int32_t>(), cand,
+                                        slice_counts, c->stream);
+        } else if (tile_path) {
             launch_sift_select_tile(c->d_pairs.as<SiftPair>(), npairs, max_rows, max_chunks, c->d_rr1.as<int32_t>(),
                                     c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, slice_counts, c->stream);
             launch_sift_resolve(c->d_pairs.as<SiftPair>(), npairs, max_rows, rule, cand, c->stream);

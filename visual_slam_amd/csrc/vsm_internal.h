@@ -204,6 +204,14 @@ void launch_sift_query_tile(const SiftPair* pairs, const SiftItem* items, int ni
 constexpr int kMaxRowSlices = 64;
 int sift_select_slices(int max_rows);
 int sift_verify_rows_slices(int max_rows);
+// The tile-minimum query pass with the select and resolve passes in its tail, and (finish) the rescan pass and the pass
+// that gathers the strips' candidate segments: for submissions whose every pair has at most kChunkCols rows in either set.
+// seg_counts: kChunkCols / kStripRows ints per pair of scratch.
+void launch_sift_query_tile_fused(const SiftPair* pairs, int npairs, const SiftItem* items, int nitems,
+                                  int32_t* rr_y1, MatchRule rule, SiftCandidates cand, int32_t* seg_counts,
+                                  hipStream_t s);
+void launch_sift_fused_finish(const SiftPair* pairs, int npairs, MatchRule rule, SiftCandidates cand,
+                              const int32_t* seg_counts, hipStream_t s);
 void launch_sift_select_tile(const SiftPair* pairs, int npairs, int max_rows, int max_chunks, int32_t* rr_y1,
                              int32_t* rr_tile, int32_t* rr_k2, MatchRule rule, SiftCandidates cand,
                              int32_t* slice_counts, hipStream_t s);
