@@ -350,7 +350,7 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
                                      "submission shape (profiles/r02_probe1000_pmc_*.csv; FETCH_SIZE doubled as gfx950 needs), "
                                      "not a measurement of this run; algorithmic operand bytes per launch: %d"
                                      % (launch_pairs * 2 * nfeat * 128),
-                     "kernel": "sift_query_tile_kernel" if m.last_u8_path() == 0 else "sift_query_kernel", "kernel_ms": kms,
+                     "kernel": "sift_query_tile_kernel" if m.last_u8_path() in (0, 2) else "sift_query_kernel", "kernel_ms": kms,
                      "verify_kernel_ms": float(np.mean(verify_ms)),
                      "note": "int8 ops: 256 per descriptor pair (128 MAC), one direction counted once"},
     }
@@ -549,7 +549,7 @@ def run_sift_large_pair(args, torch, dist, world, rank):
                    "parallelism": "replicas x%d" % world, "matches": int(tot)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                      "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": None,
-                     "kernel": "sift_query_tile_kernel" if m.last_u8_path() == 0 else "sift_query_kernel", "kernel_ms": kms},
+                     "kernel": "sift_query_tile_kernel" if m.last_u8_path() in (0, 2) else "sift_query_kernel", "kernel_ms": kms},
     }
     if world == 1 and not args.no_cpu_baseline:
         sets = [arena[i, :8192].cpu().numpy() for i in range(2)]

@@ -111,10 +111,15 @@ int vsm_last_f32_reverse(const vsm_ctx* ctx);
  *     exact distance and tests for the few candidates afterwards; their mutual check looks only at the
  *     image-0 rows near enough to anything to matter.  Everything else (no ratio test, raw 2-NN) runs the
  *     packed form.
- *   VSM_U8_PACKED: the packed form only (value and row in one key for every distance). */
-enum { VSM_U8_AUTO = 0, VSM_U8_PACKED = 1 };
+ *     In a submission of eight pairs or more whose sets all have at most 8192 rows, the settling of a strip of 512
+ *     query rows runs in the tail of the query kernel itself, while the train image is still in the cache.
+ *   VSM_U8_PACKED: the packed form only (value and row in one key for every distance).
+ *   VSM_U8_TILE_SEPARATE / VSM_U8_TILE_FUSED: as VSM_U8_AUTO, with the settling always in passes of its own /
+ *     in the query kernel's tail whenever the sets' sizes allow it, whatever the number of pairs. */
+enum { VSM_U8_AUTO = 0, VSM_U8_PACKED = 1, VSM_U8_TILE_SEPARATE = 2, VSM_U8_TILE_FUSED = 3 };
 int vsm_set_u8_mode(vsm_ctx* ctx, int mode);
-/* Which query pass the last u8 submission ran: 0 = tile-minimum, 1 = packed (-1: none yet). */
+/* Which query pass the last u8 submission ran: 0 = tile-minimum, 1 = packed, 2 = tile-minimum with the candidates
+ * settled in its tail (-1: none yet). */
 int vsm_last_u8_path(const vsm_ctx* ctx);
 int vsm_release_set(vsm_ctx* ctx, int set);
 int vsm_set_count(const vsm_ctx* ctx, int set);

@@ -10,10 +10,11 @@ from visual_slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[0, 1], ids=["tilemin", "packed"])
+@pytest.fixture(autouse=True, params=[0, 1, 3], ids=["tilemin", "packed", "tilemin-fused"])
 def u8_mode(matcher, request):
-    """Every test runs twice: with the tile-minimum query pass for ratio-test submissions (default), and
-    with the packed form only.  Same bits are demanded of both."""
+    """Every test runs three times: with the tile-minimum query pass for ratio-test submissions (default: candidates
+    settled in the query kernel's tail for lists of eight pairs or more), with the packed form only, and with the
+    tail form forced for every submission whose sizes allow it.  Same bits are demanded of all."""
     matcher.set_u8_mode(request.param)
     yield request.param
     matcher.set_u8_mode(0)
@@ -255,7 +256,7 @@ def test_tile_minimum_path_is_the_one_that_runs(matcher, u8_mode):
     s0, s1 = matcher.upload_u8(a), matcher.upload_u8(b)
     try:
         matcher.match_pair(s0, s1, ratio=0.8, mutual=True)
-        assert matcher.last_u8_path() == u8_mode          # 0: tile-minimum, 1: packed
+        assert matcher.last_u8_path() == {0: 0, 1: 1, 3: 2}[u8_mode]   # 0: tile-minimum, 1: packed, 2: tile-minimum with the tail
         matcher.match_pair(s0, s1, ratio=None, mutual=True)
         assert matcher.last_u8_path() == 1                # no ratio test: packed form in either mode
         matcher.knn2(s0, s1)

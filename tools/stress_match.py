@@ -69,7 +69,7 @@ def one_u8(m, rng):
     num, den = ((int(rng.integers(1, 13)), 12) if rng.random() < 0.85 else (0, 1))
     mutual = bool(rng.random() < 0.7)
     cap = int(rng.integers(0, 150000)) if rng.random() < 0.25 else -1
-    m.set_u8_mode(vsm.U8_AUTO if rng.random() < 0.8 else vsm.U8_PACKED)
+    m.set_u8_mode(int(rng.choice([vsm.U8_AUTO, vsm.U8_TILE_FUSED, vsm.U8_TILE_FUSED, vsm.U8_TILE_SEPARATE, vsm.U8_PACKED])))
     s0, s1 = m.upload_u8(a), m.upload_u8(b)
     try:
         g0, g1, gd = m.match_pair(s0, s1, ratio=(num / den if num else None), mutual=mutual, max_dist_sq=cap, return_dist=True)

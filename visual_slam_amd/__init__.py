@@ -23,6 +23,8 @@ from ._binding import (  # noqa: F401
     F32_MFMA_F32,
     U8_AUTO,
     U8_PACKED,
+    U8_TILE_SEPARATE,
+    U8_TILE_FUSED,
 )
 from .host import (  # noqa: F401
     generate_imagePairs,
@@ -55,7 +57,7 @@ from .host import (  # noqa: F401
 __all__ = [
     "VsmError", "Matcher", "lib", "lib_path",
     "METRIC_DOT", "METRIC_L2", "LAYOUT_ROWS", "LAYOUT_DIM_MAJOR", "NO_SECOND",
-    "F32_FAST_EXACT", "F32_MFMA_F32", "F32_REVERSE_AUTO", "F32_REVERSE_CANDIDATES", "F32_REVERSE_ALL", "U8_AUTO", "U8_PACKED",
+    "F32_FAST_EXACT", "F32_MFMA_F32", "F32_REVERSE_AUTO", "F32_REVERSE_CANDIDATES", "F32_REVERSE_ALL", "U8_AUTO", "U8_PACKED", "U8_TILE_SEPARATE", "U8_TILE_FUSED",
     "generate_imagePairs", "generate_exhaustive_pairs", "get_list_matching_pairs",
     "sort_scores", "sort_feature_Or_descriptors", "get_correct_new_matching_index", "resort_pair_by_score",
     "save_matching_sfm", "save_feature_locations", "read_feature_locations",

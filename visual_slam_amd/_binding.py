@@ -13,6 +13,8 @@ F32_MFMA_F32 = 1
 F32_REVERSE_AUTO, F32_REVERSE_CANDIDATES, F32_REVERSE_ALL = 0, 1, 2
 U8_AUTO = 0
 U8_PACKED = 1
+U8_TILE_SEPARATE = 2
+U8_TILE_FUSED = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -241,7 +241,9 @@ int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
         sp.nA = A->n; sp.nB = B->n; sp.nA_pad = A->n_pad; sp.nB_pad = B->n_pad;
         const bool empty = A->n == 0 || B->n == 0;
         sp.nstrips = empty ? 0 : A->n_pad / kStripRows;
-        const int chunk_cols = empty ? kChunkCols : chunk_cols_for(strips_total, B->n_pad);
+        // (the forced tail form wants every train set in one chunk, also where a lone small pair would otherwise be
+        // cut into several to fill the chip)
+        const int chunk_cols = empty || c->u8_mode == VSM_U8_TILE_FUSED ? kChunkCols : chunk_cols_for(strips_total, B->n_pad);
         sp.chunk_cols = chunk_cols;
         sp.pad0 = 0;
         sp.nchunks = empty ? 0 : (B->n_pad + chunk_cols - 1) / chunk_cols;
@@ -301,12 +303,14 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     }
     // The tile-minimum query pass leaves row and exact distances to a resolve pass over the candidates: it
     // pays when the ratio test keeps the candidates few, and it does not produce the raw 2-NN outputs.
-    const bool tile_path = c->u8_mode == 0 && !o.packed_only && rule.num2 > 0 && !o.want_knn;
+    const bool tile_path = c->u8_mode != VSM_U8_PACKED && !o.packed_only && rule.num2 > 0 && !o.want_knn;
     // select and resolve passes in the tail of the query pass: every pair at most one chunk of rows on either side
     // (a call with a pair or two is bound by its launches, and this form has one more of them)
-    bool fused = tile_path && nitems > 0 && npairs >= 8 && getenv("VSM_NO_FUSED") == nullptr;
+    bool fused = tile_path && nitems > 0 && c->u8_mode != VSM_U8_TILE_SEPARATE &&
+                 (npairs >= 8 || c->u8_mode == VSM_U8_TILE_FUSED);
     for (const SiftPair& sp : pl.pairs) fused = fused && sp.nchunks <= 1 && sp.nstrips <= kChunkCols / kStripRows;
-    c->last_u8_path = nitems ? (tile_path ? 0 : 1) : c->last_u8_path;
+    c->last_u8_path = nitems ? (tile_path ? (fused ? 2 : 0) : 1) : c->last_u8_path;
+
     HIPCHK(c, c->d_slot0.ensure(out0 * 4));
     HIPCHK(c, c->d_slot1.ensure(out0 * 4));
     if (o.want_dist) HIPCHK(c, c->d_slotd.ensure(out0 * 4));
@@ -722,7 +726,7 @@ extern "C" int vsm_upload_f32_device(vsm_ctx* c, const void* des_dev, int n, int
 extern "C" int vsm_set_u8_mode(vsm_ctx* c, int mode)
 {
     if (!c) return VSM_EINVAL;
-    if (mode != VSM_U8_AUTO && mode != VSM_U8_PACKED) return fail(c, VSM_EINVAL, "unknown u8 mode %d", mode);
+    if (mode < VSM_U8_AUTO || mode > VSM_U8_TILE_FUSED) return fail(c, VSM_EINVAL, "unknown u8 mode %d", mode);
     c->u8_mode = mode;
     return VSM_OK;
 }
