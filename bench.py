@@ -339,9 +339,9 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
                      "frac": achieved / INT8_DENSE_PEAK_TOPS,
                      "frac_step": OPS_PER_EVAL_U8 * float(pps) * nfeat * nfeat / (dt / args.steps) / 1e12
                                   / INT8_DENSE_PEAK_TOPS,
-                     "traffic": measured_traffic("vsm::sift_query_tile_kernel")
+                     "traffic": measured_traffic("void vsm::sift_query_tile_kernel<true>")
                      if (nimg, nfeat, launch_pairs) == (1000, 8192, 2048) else None,
-                     "mfma_busy_frac": measured_mfma_busy("vsm::sift_query_tile_kernel")
+                     "mfma_busy_frac": measured_mfma_busy("void vsm::sift_query_tile_kernel<true>")
                      if (nimg, nfeat, launch_pairs) == (1000, 8192, 2048) else None,
                      "mfma_busy_note": "matrix-pipe busy cycles / (elapsed cycles x SIMDs): a constant read from a committed "
                                        "counter pass over the same submission shape (profiles/r02_mfma_utilisation.txt), "

@@ -127,10 +127,10 @@ def test_bench_finds_the_committed_counter_figures():
     sys.path.insert(0, ROOT)
     import bench
 
-    sift = bench.measured_traffic("vsm::sift_query_tile_kernel")
+    sift = bench.measured_traffic("void vsm::sift_query_tile_kernel<true>")
     assert sift is not None and 1e9 < sift < 4.3e9          # below the algorithmic operand bytes of one launch
     coarse = bench.measured_traffic("void vsm::bf16_coarse_kernel<256, false, false>", "r02_traffic_db_query.json")
     assert coarse is not None and 5e8 < coarse < 3e9        # the bf16 database is 0.52 GB
-    busy = bench.measured_mfma_busy("vsm::sift_query_tile_kernel")
+    busy = bench.measured_mfma_busy("void vsm::sift_query_tile_kernel<true>")
     assert busy is not None and 0.5 < busy < 1.0
     assert bench.shard_bounds(10, 3, 0) == (0, 3) and bench.shard_bounds(10, 3, 2) == (6, 10)
