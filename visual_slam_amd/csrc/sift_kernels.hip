@@ -660,7 +660,8 @@ void sift_gather_segments_kernel(const SiftPair* __restrict__ pairs, const int32
     const SiftPair pw = pairs[blockIdx.x];
     const int tid = threadIdx.x;
     int base = 0;
-    for (int sidx = 0; sidx < pw.nstrips; ++sidx) {
+    const int nstrips = pw.nchunks > 0 ? pw.nstrips : 0;   // a pair with an empty set has no work items: nothing wrote its counts
+    for (int sidx = 0; sidx < nstrips; ++sidx) {
         const int n = seg_counts[blockIdx.x * (kChunkCols / kStripRows) + sidx];
         const size_t src = pw.out0_off + (size_t)sidx * kStripRows + tid;
         int i = 0, j = 0, d = 0;
