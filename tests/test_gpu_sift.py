@@ -471,3 +471,31 @@ def test_pairs_of_many_rows_are_cut_into_slices(matcher):
     finally:
         for s in ids:
             matcher.release(s)
+
+
+def test_empty_sets_in_a_list_that_follows_a_full_one(matcher):
+    """Eight pairs or more run the tail form of the query pass, whose strips leave per-strip candidate counts in
+    scratch memory.  A pair with an empty train set has no strips at work: the counts a previous, full submission
+    left at its place must not be read."""
+    rng = np.random.default_rng(77)
+    base = synth.sift_like(900, rng)
+    imgs = []
+    for n in (900, 700, 1100):
+        x = synth.sift_like(n, rng)
+        x[: n // 2] = np.clip(base[: n // 2].astype(np.int32) + rng.integers(-3, 4, (n // 2, 128)), 0, 255).astype(np.uint8)
+        imgs.append(x)
+    imgs.append(np.zeros((0, 128), np.uint8))
+    ids = [matcher.upload_u8(x) for x in imgs]
+    try:
+        full = [(0, 1), (1, 2), (2, 0), (0, 2), (1, 0), (2, 1), (0, 1), (1, 2), (2, 0)]
+        holes = [(0, 3), (3, 0), (1, 3), (0, 1), (3, 3), (2, 3), (3, 1), (1, 2), (2, 3)]
+        for pairs in (full, holes, full, holes):
+            off, i0, i1 = matcher.match_pairs([[ids[i], ids[j]] for i, j in pairs], ratio=0.8, mutual=True)
+            for k, (i, j) in enumerate(pairs):
+                o0, o1, _ = orc.match_u8(imgs[i], imgs[j], orc.params((4, 5), True))
+                np.testing.assert_array_equal(i0[off[k]:off[k + 1]], o0)
+                np.testing.assert_array_equal(i1[off[k]:off[k + 1]], o1)
+            assert off[-1] == len(i0)
+    finally:
+        for s in ids:
+            matcher.release(s)

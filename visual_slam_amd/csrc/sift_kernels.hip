@@ -1046,8 +1046,10 @@ void sift_verify_rows_kernel(const SiftPair* __restrict__ pairs, const int32_t* 
     const int pair = blockIdx.y, sl = blockIdx.x, nsl = gridDim.x;
     const SiftPair pw = pairs[pair];
     const int tid = threadIdx.x;
-    const int span = ((pw.nA + nsl - 1) / nsl + 1024 * R - 1) / (1024 * R) * (1024 * R);
-    const int lo = min(sl * span, pw.nA), hi = min(lo + span, pw.nA);
+    // a pair with an empty train set has no query-pass records at all (its row_off is the next pair's): no rows to look at
+    const int nrows = pw.nchunks > 0 ? pw.nA : 0;
+    const int span = ((nrows + nsl - 1) / nsl + 1024 * R - 1) / (1024 * R) * (1024 * R);
+    const int lo = min(sl * span, nrows), hi = min(lo + span, nrows);
     if (tid == 0) {
         int base = 0;
         if (!COUNT)
