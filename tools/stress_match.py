@@ -87,7 +87,7 @@ def one_u8_list(m, rng):
     imgs = []
     base_a, _ = u8_data(rng, 1500, 1)
     for _ in range(nimg):
-        n = int(rng.integers(0, 2500))
+        n = 0 if rng.random() < 0.08 else int(rng.integers(0, 2500))   # empty sets inside a list now and then
         d, _ = u8_data(rng, n, 1)
         k = min(n, len(base_a)) // 2
         if k:
@@ -96,6 +96,7 @@ def one_u8_list(m, rng):
     ids = [m.upload_u8(d) for d in imgs]
     pairs = [(int(rng.integers(0, nimg)), int(rng.integers(0, nimg))) for _ in range(int(rng.integers(1, 30)))]
     mutual = bool(rng.random() < 0.7)
+    m.set_u8_mode(int(rng.choice([vsm.U8_AUTO, vsm.U8_TILE_FUSED, vsm.U8_TILE_SEPARATE, vsm.U8_PACKED])))
     try:
         off, i0, i1 = m.match_pairs([[ids[a], ids[b]] for a, b in pairs], ratio=0.8, mutual=mutual)
         ok = True
@@ -104,6 +105,7 @@ def one_u8_list(m, rng):
             ok = ok and np.array_equal(i0[off[k]:off[k + 1]], o0) and np.array_equal(i1[off[k]:off[k + 1]], o1)
         return ok, "u8 list of %d pairs over %d images mutual=%d matches=%d" % (len(pairs), nimg, mutual, off[-1])
     finally:
+        m.set_u8_mode(vsm.U8_AUTO)
         for s in ids:
             m.release(s)
 
