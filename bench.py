@@ -83,6 +83,13 @@ def parse():
     ap.add_argument("--images", type=int, default=1000)
     ap.add_argument("--features", type=int, default=8192)
     ap.add_argument("--pairs-per-step", type=int, default=2048)
+    ap.add_argument("--data", default="planted", choices=["planted", "clustered", "duplicates", "ones"],
+                    help="sift_exhaustive: what the synthetic descriptors look like (planted: random rows with 30 %% "
+                         "noisy copies of a shared pool; clustered: every row within +-2 of one of 12 centres; duplicates: "
+                         "rows drawn from a pool of 200, a third of them with one byte changed by one; ones: every byte 1, "
+                         "the dummy descriptors of FeaturePoints.cpp:358-367)")
+    ap.add_argument("--u8-mode", type=int, default=0, help="sift workloads: vsm_set_u8_mode (0 auto, 1 packed form only, "
+                                                           "2 / 3 tile-minimum form with separate passes / fused tail)")
     ap.add_argument("--f32-mode", type=int, default=0,
                     help="float workloads: 0 = bf16 coarse pass + exact re-rank, 1 = f32-input MFMA kernel only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -203,10 +210,13 @@ def sum_over_ranks(torch, dist, world, v):
     return float(t.item())
 
 
-def gen_sift_arena(torch, nimg, nfeat, seed):
+def gen_sift_arena(torch, nimg, nfeat, seed, data="planted"):
     """SIFT-like u8 descriptors on the device: |N(0,1)| components, L2-normalised to 512, rounded
     (the convention of FeaturePoints.cpp:680-684).  30 % of every image's rows are noisy copies of
-    rows of a shared 'scene' pool, so image pairs have real correspondences."""
+    rows of a shared 'scene' pool, so image pairs have real correspondences.
+    Other values of `data` build the inputs the matcher likes least: rows in tight clusters, rows drawn from a small
+    pool (exact duplicates and rows one unit apart everywhere), or the all-ones dummy descriptors the reference's own
+    converter writes (FeaturePoints.cpp:358-367), where every distance is tied."""
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
 
@@ -215,8 +225,25 @@ def gen_sift_arena(torch, nimg, nfeat, seed):
         x *= 512.0 / x.norm(dim=1, keepdim=True).clamp_min(1e-6)
         return x
 
-    pool = raw(nfeat)
     arena = torch.empty((nimg, nfeat, 128), dtype=torch.uint8, device="cuda")
+    if data == "ones":
+        arena.fill_(1)
+        torch.cuda.synchronize()
+        return arena
+    if data in ("clustered", "duplicates"):
+        centres = raw(12 if data == "clustered" else 200).round_().clamp_(0, 255)
+        for i in range(nimg):
+            x = centres[torch.randint(0, len(centres), (nfeat,), generator=g, device="cuda")].clone()
+            if data == "clustered":
+                x += torch.randint(-2, 3, (nfeat, 128), generator=g, device="cuda").float()
+            else:
+                rows = torch.randperm(nfeat, generator=g, device="cuda")[: nfeat // 3]
+                cols = torch.randint(0, 128, (len(rows),), generator=g, device="cuda")
+                x[rows, cols] = (x[rows, cols].to(torch.int32) ^ 1).float()
+            arena[i] = x.clamp_(0, 255).to(torch.uint8)
+        torch.cuda.synchronize()
+        return arena
+    pool = raw(nfeat)
     k = int(0.3 * nfeat)
     for i in range(nimg):
         x = raw(nfeat)
@@ -259,8 +286,9 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
     import visual_slam_amd as vsm
 
     nimg, nfeat, pps = args.images, args.features, args.pairs_per_step
-    arena = gen_sift_arena(torch, nimg, nfeat, seed=1234)
+    arena = gen_sift_arena(torch, nimg, nfeat, seed=1234, data=args.data)
     m = vsm.Matcher(torch.cuda.current_device())
+    m.set_u8_mode(args.u8_mode)
     ids = [m.upload_u8_device(arena[i].data_ptr(), nfeat) for i in range(nimg)]
     pairs_all = vsm.generate_exhaustive_pairs(nimg)
     # contiguous shard per rank: consecutive pairs share image 0, so it stays cache-resident
@@ -333,9 +361,10 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
         "config": {"workload": "exhaustive SIFT-128 matching, %d images x %d features, ratio 0.8 + mutual, "
                                "%d pairs per step per GPU, two steps in flight, match lists copied to host"
                                % (nimg, nfeat, pps),
+                   "data": args.data, "u8_mode": args.u8_mode,
                    "pairs_total": int(len(pairs_all)), "parallelism": "pair list sharded x%d" % world,
                    "matches_per_pair": nmatch / max(npairs, 1)},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TOP/s",
                      "frac": achieved / INT8_DENSE_PEAK_TOPS,
                      "frac_step": OPS_PER_EVAL_U8 * float(pps) * nfeat * nfeat / (dt / args.steps) / 1e12
                                   / INT8_DENSE_PEAK_TOPS,
@@ -547,7 +576,7 @@ def run_sift_large_pair(args, torch, dist, world, rank):
         "vs_baseline": None, "dtype": "u8", "data": "synthetic", "verified": verified,
         "config": {"workload": "one SIFT-128 pair of 65536 x 65536 features, ratio 0.8 + mutual",
                    "parallelism": "replicas x%d" % world, "matches": int(tot)},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TOP/s",
                      "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": None,
                      "kernel": "sift_query_tile_kernel" if m.last_u8_path() in (0, 2) else "sift_query_kernel", "kernel_ms": kms},
     }
@@ -686,7 +715,7 @@ def run_shortlist(args, torch, dist, world, rank):
         "config": {"workload": "vocabulary shortlist, %d images x %d SIFT-128 features, %d words, %d partners per image"
                                % (nimg, nfeat, nwords, topk),
                    "parallelism": "replicas only", "pairs_listed": int(len(pairs))},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TOP/s",
                      "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": None, "kernel": "sift_query_kernel",
                      "kernel_ms": kms,
                      "note": "kernel_ms = the word-assignment launch (descriptors x words distances)"},

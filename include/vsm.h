@@ -121,6 +121,14 @@ int vsm_set_u8_mode(vsm_ctx* ctx, int mode);
 /* Which query pass the last u8 submission ran: 0 = tile-minimum, 1 = packed, 2 = tile-minimum with the candidates
  * settled in its tail (-1: none yet). */
 int vsm_last_u8_path(const vsm_ctx* ctx);
+/* Rows of the last finished u8 submission (collected, or matched by a call that waits) that the tile-minimum form
+ * could not settle from its query pass and sent through the rescan pass: a second, packed-form pass over the whole
+ * train set for those rows only.  0 for the packed form; -1: none yet.  A handful per pair on ordinary data; every row
+ * on data full of exact duplicates (e.g. the all-ones descriptors of FeaturePoints.cpp:358-367), which is the worst
+ * case of that form: the two passes together.  Under VSM_U8_AUTO a submission in which more than one row in eight
+ * went that way makes the next 31 submissions of the context run the packed form, after which the tile-minimum form
+ * is tried again. */
+int vsm_last_u8_rescanned(const vsm_ctx* ctx);
 int vsm_release_set(vsm_ctx* ctx, int set);
 int vsm_set_count(const vsm_ctx* ctx, int set);
 

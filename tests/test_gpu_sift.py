@@ -499,3 +499,76 @@ def test_empty_sets_in_a_list_that_follows_a_full_one(matcher):
     finally:
         for s in ids:
             matcher.release(s)
+
+
+def _degenerate_images(rng):
+    """Sets on which every nearest distance is tied: the all-ones dummy descriptors the reference's converter writes
+    (FeaturePoints.cpp:358-367), and rows drawn from a pool of 40 with a third of them one unit off in one byte."""
+    ones = [np.ones((n, 128), np.uint8) for n in (2048, 2048, 1500, 2048)]
+    pool = synth.sift_like(40, rng)
+    dups = []
+    for n in (2048, 1800, 2048, 700):
+        x = pool[rng.integers(0, 40, n)].copy()
+        rows = rng.choice(n, n // 3, replace=False)
+        x[rows, rng.integers(0, 128, len(rows))] ^= 1
+        dups.append(np.ascontiguousarray(x))
+    return ones, dups
+
+
+def test_all_ones_and_duplicate_sets_take_the_rescan_pass(matcher, u8_mode):
+    """Data full of exact duplicates: the tile-minimum form cannot settle a single row from its query pass, every row
+    goes through the rescan pass (the packed form over gathered rows), and the lists still equal the oracle's."""
+    rng = np.random.default_rng(101)
+    for imgs in _degenerate_images(rng):
+        ids = [matcher.upload_u8(x) for x in imgs]
+        pairs = [(i, j) for i in range(4) for j in range(4) if i != j][:10]
+        try:
+            for mutual in (True, False):
+                matcher.set_u8_mode(u8_mode)   # (forgets what the default mode learnt from the last list)
+                off, i0, i1 = matcher.match_pairs([[ids[i], ids[j]] for i, j in pairs], ratio=0.8, mutual=mutual)
+                rescanned = matcher.last_u8_rescanned()
+                for k, (i, j) in enumerate(pairs):
+                    o0, o1, _ = orc.match_u8(imgs[i], imgs[j], orc.params((4, 5), mutual))
+                    np.testing.assert_array_equal(i0[off[k]:off[k + 1]], o0)
+                    np.testing.assert_array_equal(i1[off[k]:off[k + 1]], o1)
+                rows = sum(len(imgs[i]) for i, _ in pairs)
+                if u8_mode == 1:
+                    assert rescanned == 0 and matcher.last_u8_path() == 1
+                else:
+                    assert matcher.last_u8_path() == (2 if u8_mode == 3 else 0)   # (a short list of small sets is cut into chunks)
+                    assert rescanned > rows // 2, "%d of %d rows rescanned" % (rescanned, rows)
+            matcher.set_u8_mode(u8_mode)
+            g0, g1, gd = matcher.match_pair(ids[0], ids[1], ratio=0.8, mutual=True, return_dist=True)
+            o0, o1, od = orc.match_u8(imgs[0], imgs[1], orc.params((4, 5), True))
+            np.testing.assert_array_equal(g0, o0)
+            np.testing.assert_array_equal(g1, o1)
+            np.testing.assert_array_equal(gd, od)
+            if u8_mode != 1:
+                assert matcher.last_u8_rescanned() > len(imgs[0]) // 2
+        finally:
+            for s in ids:
+                matcher.release(s)
+
+
+def test_default_mode_goes_to_the_packed_form_after_a_submission_of_duplicates(matcher, u8_mode):
+    """VSM_U8_AUTO: a submission in which more than one row in eight needed the rescan pass sends the next 31
+    submissions through the packed form; the 32nd tries the tile-minimum form again.  Forced modes never change form."""
+    rng = np.random.default_rng(102)
+    ones, _ = _degenerate_images(rng)
+    a, b = synth.sift_pair(600, 900, seed=103)
+    ids = [matcher.upload_u8(x) for x in ones[:2]] + [matcher.upload_u8(a), matcher.upload_u8(b)]
+    o0, o1, _ = orc.match_u8(a, b, orc.params((4, 5), True))
+    tile = {0: 0, 1: 1, 3: 2}[u8_mode]
+    try:
+        matcher.match_pairs([[ids[0], ids[1]]] * 8, ratio=0.8, mutual=True)
+        assert matcher.last_u8_path() == {0: 0, 1: 1, 3: 2}[u8_mode]
+        assert matcher.last_u8_rescanned() == (0 if u8_mode == 1 else 8 * 2048)
+        for k in range(33):
+            g0, g1 = matcher.match_pair(ids[2], ids[3], ratio=0.8, mutual=True)
+            np.testing.assert_array_equal(g0, o0)
+            np.testing.assert_array_equal(g1, o1)
+            want = 1 if (u8_mode == 0 and k < 31) else tile
+            assert matcher.last_u8_path() == want, "submission %d after the duplicates ran form %d" % (k, matcher.last_u8_path())
+    finally:
+        for s in ids:
+            matcher.release(s)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Matrix-core utilisation of the float kernels: one rocprofv3 --pmc pass each over the database query
+# (tools/db_query_probe.py) and the float pair lists (tools/f32_pairs_probe.py), folded by tools/pmc_fold.py.
+# usage: tools/bf16_counters.sh TAG     (run on the GPU box; results land in gpurun_out/prof/)
+tag=${1:-r03}
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/gpurun_out/prof
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+counters="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"
+pass() {   # name, probe script and its arguments
+  name=$1; shift
+  rm -rf /tmp/pmc_$name
+  timeout -s KILL 240 rocprofv3 --pmc $counters --kernel-trace --output-format csv -d /tmp/pmc_$name -- python3 "$@" > /tmp/pmc_$name.log 2>&1 || { tail -5 /tmp/pmc_$name.log; return 1; }
+  cp "$(find /tmp/pmc_$name -name '*counter_collection.csv' | head -1)" $out/${tag}_${name}_pmc_mfma.csv
+  python3 $root/tools/pmc_fold.py $out/${tag}_${name}_pmc_mfma.csv bf16_ f32_ | tee $out/${tag}_${name}_mfma_utilisation.txt
+}
+pass dbquery $root/tools/db_query_probe.py && pass f32pairs $root/tools/f32_pairs_probe.py

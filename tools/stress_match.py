@@ -17,7 +17,7 @@ from visual_slam_amd import synth  # noqa: E402
 
 
 def u8_data(rng, n0, n1):
-    kind = rng.integers(0, 6)
+    kind = rng.integers(0, 7)
     if kind == 0:      # plain SIFT-like with planted matches
         a, b = synth.sift_pair(max(n0, 1), max(n1, 1), seed=int(rng.integers(1 << 30)), planted=float(rng.uniform(0, 0.7)),
                                noise=float(rng.uniform(1, 14)))
@@ -43,9 +43,17 @@ def u8_data(rng, n0, n1):
         lo = int(rng.choice([0, 120, 250]))
         a = rng.integers(lo, lo + 6, (n0, 128)).astype(np.uint8)
         b = rng.integers(lo, lo + 6, (n1, 128)).astype(np.uint8)
-    else:              # full-range random bytes
+    elif kind == 5:    # full-range random bytes
         a = rng.integers(0, 256, (n0, 128)).astype(np.uint8)
         b = rng.integers(0, 256, (n1, 128)).astype(np.uint8)
+    else:              # every row the same (the dummy descriptors of FeaturePoints.cpp:358-367), a few rows one unit off
+        v = int(rng.choice([0, 1, 128, 255]))
+        a = np.full((n0, 128), v, np.uint8)
+        b = np.full((n1, 128), v, np.uint8)
+        for arr in (a, b):
+            k = len(arr) // int(rng.choice([3, 50, 10**9]))
+            if k:
+                arr[rng.integers(0, len(arr), k), rng.integers(0, 128, k)] ^= 1
     if n0 and n1 and rng.random() < 0.5:
         k = min(n0, n1, int(rng.integers(1, 60)))
         b[rng.integers(0, n1, k)] = a[rng.integers(0, n0, k)]

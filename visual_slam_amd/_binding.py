@@ -64,6 +64,7 @@ SIGNATURES = {
     "vsm_last_f32_path": (C.c_int, [C.c_void_p]),
     "vsm_set_u8_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "vsm_last_u8_path": (C.c_int, [C.c_void_p]),
+    "vsm_last_u8_rescanned": (C.c_int, [C.c_void_p]),
     "vsm_release_set": (C.c_int, [C.c_void_p, C.c_int]),
     "vsm_set_count": (C.c_int, [C.c_void_p, C.c_int]),
     "vsm_match_pair": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_int,
@@ -472,6 +473,10 @@ class Matcher:
 
     def last_u8_path(self):
         return int(self._l.vsm_last_u8_path(self._h))
+
+    def last_u8_rescanned(self):
+        """Rows of the last finished u8 submission that needed the rescan pass (0 in the packed form)."""
+        return int(self._l.vsm_last_u8_rescanned(self._h))
 
     def last_f32_path(self):
         return int(self._l.vsm_last_f32_path(self._h))

@@ -18,6 +18,7 @@
 #include "vsm_internal.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace vsm {
 
@@ -635,14 +636,14 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
                 cand.i0[o] = i;
                 cand.vbest[o] = ~0ull;
                 if (amb) {
-                    const int e = atomicAdd(cand.rescan_count, 1);
-                    cand.rescan_list[e] = make_int2(it.pair, cpos);
+                    const int e = atomicAdd(&cand.rescan_cnt[it.pair], 1);
+                    cand.rescan_list[pw.out0_off + e] = cpos;
                     cand.j1[o] = -1;
                     cand.d1[o] = 0;
                 } else {
                     cand.j1[o] = pass ? tl * 32 + (kb >> 2) * 16 + qd * 4 + (kb & 3) : -1;
                     cand.d1[o] = (int)d1;
-                    if (pass) atomicMax(&cand.dmax[it.pair], (int)d1);
+                    if (pass && cand.dmax) atomicMax(&cand.dmax[it.pair], (int)d1);
                 }
             }
         }
@@ -763,9 +764,11 @@ void sift_select_tile_kernel(const SiftPair* __restrict__ pairs,
         if (!COUNT)
             for (int k = 0; k < sl; ++k) base += slice_counts[pair * nsl + k];
         base_s = base;
-        if (!COUNT && sl == 0) cand.dmax[pair] = INT32_MIN;
+        if (!COUNT && sl == 0) {
+            if (cand.dmax) cand.dmax[pair] = INT32_MIN;
+            cand.rescan_cnt[pair] = 0;
+        }
     }
-    if (!COUNT && pair == 0 && sl == 0 && tid == 0) *cand.rescan_count = 0;
     __syncthreads();
 
     for (int i0 = lo; i0 < hi; i0 += 1024 * R) {
@@ -856,26 +859,6 @@ void launch_sift_select_tile(const SiftPair* pairs, int npairs, int max_rows, in
 }
 
 // ---- 2c. resolve / rescan ------------------------------------------------------------------
-// nrm(q) - 2 p.q for row (lane & 31) of 32-row train tile `tile` (INT32_MAX for padding rows), the same
-// value in lanes l and l + 32.  qa: this lane's 16-byte pieces of the query row, one per k-step.
-__device__ __forceinline__ int tile_row_x(const SiftPair& pw, int tile, int lane, const v4i (&qa)[4])
-{
-    const int8_t* tb = pw.fragB + (size_t)tile * kTileBytes + lane * 16;
-    int dot = 0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) dot = dot16(qa[s], *reinterpret_cast<const v4i*>(tb + s * 1024), dot);
-    dot += __shfl_xor(dot, 32);
-    const int row = tile * 32 + (lane & 31);
-    return row < pw.nB ? (pw.nrmB[row] >> 8) - 2 * dot : INT32_MAX;
-}
-
-__device__ __forceinline__ int wave_min32(int v)   // minimum over lanes 0..31, valid in all of them
-{
-#pragma unroll
-    for (int d = 16; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
-    return v;
-}
-
 // Eight lanes per candidate, lane k = row k of the winner's 8-row group (rows 4 q .. 4 q + 3 of both 16-row
 // blocks of its tile), the whole 128-byte dot product per lane: the 8 exact distances give the nearest row
 // (lowest row among equal distances), the exact d1 and the runner-up inside the group; every row outside the
@@ -951,68 +934,260 @@ void sift_resolve_kernel(const SiftPair* __restrict__ pairs, int slices, MatchRu
                 const int c = base + k * stride;
                 const size_t o = pw.out0_off + c;
                 if (amb) {
-                    const int e = atomicAdd(cand.rescan_count, 1);
-                    cand.rescan_list[e] = make_int2(p, c);
+                    const int e = atomicAdd(&cand.rescan_cnt[p], 1);
+                    cand.rescan_list[pw.out0_off + e] = c;
                     cand.j1[o] = -1;
                 } else {
                     cand.j1[o] = pass ? tl * 32 + (kb >> 2) * 16 + quad * 4 + (kb & 3) : -1;
                     cand.d1[o] = (int)d1;
-                    if (pass) atomicMax(&cand.dmax[p], (int)d1);
+                    if (pass && cand.dmax) atomicMax(&cand.dmax[p], (int)d1);
                 }
             }
         }
     }
 }
 
-// The candidates one group could not settle: exact two nearest over the whole train set, one wave each.
-constexpr int kRescanGrid = 512;
-__global__ __launch_bounds__(kResolveWaves * 64)
-void sift_rescan_kernel(const SiftPair* __restrict__ pairs, MatchRule rule, SiftCandidates cand)
+// ---- 2d. rescan ------------------------------------------------------------------------------
+// The candidates one group could not settle get the packed form of the query pass, which is exact by itself: their
+// rows of image 0 are gathered, 512 per work item (32 per block of a wave, as in the query pass), and the item's
+// chunk of the train set streams past them.  On ordinary data a pair has none or a handful of them (one item whose
+// waves skip the blocks without rows); on data full of exact duplicates every row of every pair comes here, and the
+// pass then costs what the packed query pass costs, which bounds the tile-minimum path at the sum of the two.
+constexpr int kRescanGrid = 512;    // two workgroups per CU: the whole grid is resident and walks the item list
+
+// rescan_cnt[pair] -> (pair, block of kStripRows list slots, chunk) items; nitems[0] = their number, nitems[1] = the
+// candidates of the whole submission
+__global__ __launch_bounds__(1024)
+void sift_rescan_plan_kernel(const SiftPair* __restrict__ pairs, int npairs, const int32_t* __restrict__ counts,
+                             SiftItem* __restrict__ items, int32_t* __restrict__ nitems)
 {
-    const int total = *cand.rescan_count;
-    const int lane = threadIdx.x & 63, lane5 = lane & 31, half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int e = blockIdx.x * kResolveWaves + wave; e < total; e += gridDim.x * kResolveWaves) {
-        const int2 pc = cand.rescan_list[e];
-        const SiftPair pw = pairs[pc.x];
-        const size_t o = pw.out0_off + pc.y;
-        const int i = cand.i0[o];
-        const int8_t* qsrc = pw.fragA + (size_t)(i >> 5) * kTileBytes + (half * 32 + (i & 31)) * 16;
-        v4i qa[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qa[s] = *reinterpret_cast<const v4i*>(qsrc + s * 1024);
-        // per lane: rows lane5, lane5 + 32, ... in ascending order (strict compare keeps the lowest row)
-        int b1 = INT32_MAX, b1row = INT32_MAX, b2 = INT32_MAX;
-        const int ntiles = pw.nB_pad / 32;
-        for (int tl = 0; tl < ntiles; ++tl) {
-            const int x = tile_row_x(pw, tl, lane, qa);
-            if (x < b1) {
-                b2 = b1;
-                b1 = x;
-                b1row = tl * 32 + lane5;
-            } else {
-                b2 = min(b2, x);
-            }
+    __shared__ int wsum[16], csum[16];
+    __shared__ int carry_s, cand_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { carry_s = 0; cand_s = 0; }
+    __syncthreads();
+    for (int p0 = 0; p0 < npairs; p0 += 1024) {
+        const int p = p0 + tid;
+        const int cnt = p < npairs ? counts[p] : 0;
+        const int nch = p < npairs ? pairs[p].nchunks : 0;
+        const int blocks = (cnt + kStripRows - 1) / kStripRows;
+        const int v = blocks * nch;
+        int incl = v, cincl = cnt;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d), oc = __shfl_up(cincl, d);
+            if (lane >= d) { incl += o; cincl += oc; }
         }
-        // winner over lanes by (distance, row); runner-up = best of the other lanes' nearest and the winner lane's second
-        const int wx = wave_min32(b1);
-        const int wrow = wave_min32(b1 == wx ? b1row : INT32_MAX);
-        const int x2 = wave_min32(b1row == wrow ? b2 : b1);
-        const long long na = pw.nrmA[i] >> 8;
-        const long long d1 = (long long)wx + na;
-        bool pass = wx != INT32_MAX;
-        if (pass && x2 != INT32_MAX) pass = ratio_ok(rule, d1, (long long)x2 + na);
-        if (pass && rule.max_dist >= 0 && d1 > rule.max_dist) pass = false;
-        if (lane == 0) {
-            cand.j1[o] = pass ? wrow : -1;
-            cand.d1[o] = (int)d1;
-            if (pass) atomicMax(&cand.dmax[pc.x], (int)d1);
+        if (lane == 63) { wsum[wave] = incl; csum[wave] = cincl; }
+        __syncthreads();
+        int woff = 0, tot = 0, ctot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) woff += wsum[w];
+            tot += wsum[w];
+            ctot += csum[w];
         }
+        int at = carry_s + woff + incl - v;
+        for (int b = 0; b < blocks; ++b)
+            for (int ch = 0; ch < nch; ++ch) items[at++] = SiftItem{p, (int16_t)b, (int16_t)ch};
+        __syncthreads();
+        if (tid == 0) { carry_s += tot; cand_s += ctot; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        nitems[0] = carry_s;
+        nitems[1] = cand_s;
     }
 }
 
+// The packed query pass (see sift_query_kernel) over gathered rows: list slot k of the pair names candidate
+// rescan_list[k], whose row of image 0 is the persistent operand.  Results per (chunk, slot), as the query pass leaves
+// them per (chunk, row): exact distance of the nearest row, the row (lowest among equals), exact runner-up distance.
+__global__ __launch_bounds__(kQueryWaves * 64, 2)
+void sift_rescan_query_kernel(const SiftPair* __restrict__ pairs, SiftCandidates cand, int negscale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane5 = lane & 31;
+    const int half = lane >> 5;
+    const int total = cand.rescan_nitems[0];
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    const SiftItem it = cand.rescan_items[w];
+    const SiftPair pw = pairs[it.pair];
+    const int cnt = cand.rescan_cnt[it.pair];
+    const int c0 = it.chunk * pw.chunk_cols;
+    const int ncols = min(pw.chunk_cols, pw.nB_pad - c0);
+    const int nsteps = ncols / kStepRows;
+
+    const int slot0 = it.strip * kStripRows + wave * (kQueryRB * 32);
+    // blocks of 32 slots this wave has rows in (the same for every lane of the wave)
+    const int nlive = __builtin_amdgcn_readfirstlane(min(kQueryRB, max(0, (cnt - slot0 + 31) / 32)));
+    int qrow[kQueryRB];
+    v4i pf[kQueryRB][4];
+#pragma unroll
+    for (int rb = 0; rb < kQueryRB; ++rb) {
+        const int slot = slot0 + rb * 32 + lane5;
+        qrow[rb] = slot < cnt ? cand.i0[pw.out0_off + cand.rescan_list[pw.out0_off + slot]] : 0;
+        const int8_t* src = pw.fragA + (size_t)(qrow[rb] >> 5) * kTileBytes + (half * 32 + (qrow[rb] & 31)) * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pf[rb][s] = *reinterpret_cast<const v4i*>(src + s * 1024);
+    }
+
+    const int8_t* Bsrc = pw.fragB + (size_t)(c0 >> 5) * kTileBytes + wave * (kLdsTile / kQueryWaves) + lane * 16;
+    const int32_t* Nsrc = pw.nrmB + c0 + (wave & 3) * 64 + lane;
+
+    int bestd[kQueryRB], bestcol[kQueryRB], second[kQueryRB];
+#pragma unroll
+    for (int rb = 0; rb < kQueryRB; ++rb) { bestd[rb] = kDistPad; bestcol[rb] = INT32_MAX; second[rb] = kDistPad; }
+
+    stage_step<kQueryWaves>(smem, 0, Bsrc, Nsrc, wave);
+    __syncthreads();
+
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nsteps)
+            stage_step<kQueryWaves>(smem, cur ^ 1, Bsrc + (size_t)(st + 1) * kLdsTile, Nsrc + (st + 1) * kStepRows, wave);
+        const char* Bt = smem + cur * kLdsTile + lane * 16;
+        const int* nl = reinterpret_cast<const int*>(smem + 2 * kLdsTile + cur * kLdsNorm);
+
+        int k1[kQueryRB], k2[kQueryRB];
+#pragma unroll
+        for (int rb = 0; rb < kQueryRB; ++rb) { k1[rb] = INT32_MAX; k2[rb] = INT32_MAX; }
+
+        // all four blocks of the wave in use: the instruction stream of the query pass; else only the blocks with rows
+        auto tiles = [&](auto full) {
+            constexpr bool FULL = decltype(full)::value;
+#pragma unroll
+            for (int t = 0; t < kTilesPerStep; ++t) {
+                const char* tile = Bt + t * 4096;
+                const v4i b0 = *reinterpret_cast<const v4i*>(tile);
+                const v4i b1 = *reinterpret_cast<const v4i*>(tile + 1024);
+                const v4i b2 = *reinterpret_cast<const v4i*>(tile + 2048);
+                const v4i b3 = *reinterpret_cast<const v4i*>(tile + 3072);
+                int c[16];
+                tile_consts(nl + t * 32, half, c);
+                v16i acc[kQueryRB];
+#pragma unroll
+                for (int rb = 0; rb < kQueryRB; ++rb) {
+                    if (FULL || rb < nlive) {
+                        v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b0, pf[rb][0], z, 0, 0, 0);
+                        z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b1, pf[rb][1], z, 0, 0, 0);
+                        z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b2, pf[rb][2], z, 0, 0, 0);
+                        z = __builtin_amdgcn_mfma_i32_32x32x32_i8(b3, pf[rb][3], z, 0, 0, 0);
+                        acc[rb] = z;
+                    }
+                }
+#pragma unroll
+                for (int rb = 0; rb < kQueryRB; ++rb) {
+                    if (FULL || rb < nlive) {
+                        int uprev = 0;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int x0 = __mul24(acc[rb][2 * e], negscale) + c[2 * e];
+                            const int x1 = __mul24(acc[rb][2 * e + 1], negscale) + c[2 * e + 1];
+                            const int u = med3i(k1[rb], x0, x1);   // runner-up of {k1, x0, x1}
+                            k1[rb] = min3i(k1[rb], x0, x1);
+                            if (e & 1) k2[rb] = min3i(k2[rb], uprev, u);
+                            uprev = u;
+                        }
+                    }
+                }
+            }
+        };
+        if (nlive == kQueryRB) tiles(std::true_type{});
+        else if (nlive > 0) tiles(std::false_type{});
+#pragma unroll
+        for (int rb = 0; rb < kQueryRB; ++rb) {
+            // fold the finished 256-row group (strict compare: the earlier group, i.e. the lower row, stays)
+            const int d = k1[rb] >> 8;
+            const int col = c0 + st * kStepRows + (k1[rb] & 255);
+            if (d < bestd[rb]) {
+                second[rb] = min(second[rb], bestd[rb]);
+                bestd[rb] = d;
+                bestcol[rb] = col;
+            } else {
+                second[rb] = min(second[rb], d);
+            }
+            second[rb] = min(second[rb], k2[rb] >> 8);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int rb = 0; rb < kQueryRB; ++rb) {
+        int bd = bestd[rb], bc = bestcol[rb], sc = second[rb];
+        const int od = __shfl_xor(bd, 32);
+        const int oc = __shfl_xor(bc, 32);
+        const int os = __shfl_xor(sc, 32);
+        const bool other_wins = od < bd || (od == bd && oc < bc);
+        const int loser = other_wins ? bd : od;
+        if (other_wins) {
+            bd = od;
+            bc = oc;
+        }
+        sc = min(min(sc, os), loser);
+        const int slot = slot0 + rb * 32 + lane5;
+        if (half == 0 && slot < cnt) {
+            const int na = pw.nrmA[qrow[rb]] >> 8;
+            const size_t o = pw.row_off + (size_t)it.chunk * pw.nA_pad + slot;
+            cand.rs_d1[o] = bd >= kDistPad ? INT32_MAX : bd + na;
+            cand.rs_j1[o] = bc;
+            cand.rs_d2[o] = sc >= kDistPad ? INT32_MAX : sc + na;
+        }
+    }
+    }   // next work item (the last step's barrier separates it from this one's LDS reads)
+}
+
+// Merges the chunks of every rescanned candidate (ascending column ranges: a strict compare keeps the lowest row),
+// applies the exact tests and writes the candidate's record.
+__global__ __launch_bounds__(kStripRows)
+void sift_rescan_finish_kernel(const SiftPair* __restrict__ pairs, MatchRule rule, SiftCandidates cand)
+{
+    const int total = cand.rescan_nitems[0];
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        const SiftItem it = cand.rescan_items[w];
+        if (it.chunk != 0) continue;
+        const SiftPair pw = pairs[it.pair];
+        const int slot = it.strip * kStripRows + threadIdx.x;
+        if (slot >= cand.rescan_cnt[it.pair]) continue;
+        int d1 = INT32_MAX, j1 = -1, d2 = INT32_MAX;
+        for (int c = 0; c < pw.nchunks; ++c) {
+            const size_t o = pw.row_off + (size_t)c * pw.nA_pad + slot;
+            const int e1 = cand.rs_d1[o], ej = cand.rs_j1[o], e2 = cand.rs_d2[o];
+            if (e1 < d1) {
+                d2 = min(d1, e2);
+                d1 = e1;
+                j1 = ej;
+            } else {
+                d2 = min(d2, e1);
+            }
+        }
+        if (j1 >= pw.nB) j1 = -1;
+        bool pass = j1 >= 0;
+        if (pass && d2 != INT32_MAX) pass = ratio_ok(rule, d1, d2);
+        if (pass && rule.max_dist >= 0 && (long long)d1 > rule.max_dist) pass = false;
+        const size_t o = pw.out0_off + cand.rescan_list[pw.out0_off + slot];
+        cand.j1[o] = pass ? j1 : -1;
+        cand.d1[o] = d1;
+        if (pass && cand.dmax) atomicMax(&cand.dmax[it.pair], d1);
+    }
+}
+
+void launch_sift_rescan(const SiftPair* pairs, int npairs, int max_items, MatchRule rule, SiftCandidates cand, hipStream_t s)
+{
+    if (npairs <= 0 || max_items <= 0) return;
+    hipLaunchKernelGGL(sift_rescan_plan_kernel, dim3(1), dim3(1024), 0, s, pairs, npairs, cand.rescan_cnt, cand.rescan_items,
+                       cand.rescan_nitems);
+    static DeviceFlags attr_set;   // the attribute is per device
+    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(sift_rescan_query_kernel), kLdsStream);
+    const int grid = std::min(kRescanGrid, max_items);
+    hipLaunchKernelGGL(sift_rescan_query_kernel, dim3(grid), dim3(kQueryWaves * 64), kLdsStream, s, pairs, cand, -512);
+    hipLaunchKernelGGL(sift_rescan_finish_kernel, dim3(grid), dim3(kStripRows), 0, s, pairs, rule, cand);
+}
+
 // The query pass with the select and resolve passes of every strip in its tail (every pair's sets must be one chunk
-// of rows at most); cand.rescan_count and cand.dmax are initialised here.  launch_sift_fused_finish follows it: the
+// of rows at most); cand.rescan_cnt and cand.dmax are initialised here.  launch_sift_fused_finish follows it: the
 // rescan pass over what the tails could not settle, and the gather pass over their segments.
 void launch_sift_query_tile_fused(const SiftPair* pairs, int npairs, const SiftItem* items, int nitems,
                                   int32_t* rr_y1, MatchRule rule, SiftCandidates cand, int32_t* seg_counts,
@@ -1020,16 +1195,17 @@ void launch_sift_query_tile_fused(const SiftPair* pairs, int npairs, const SiftI
 {
     static DeviceFlags attr_set;
     ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(sift_query_tile_kernel<true>), kLdsStream);
-    (void)hipMemsetAsync(cand.rescan_count, 0, sizeof(int32_t), s);
-    (void)hipMemsetAsync(cand.dmax, 0x80, sizeof(int32_t) * npairs, s);   // below every distance
+    (void)hipMemsetAsync(cand.rescan_cnt, 0, sizeof(int32_t) * npairs, s);
+    if (cand.dmax) (void)hipMemsetAsync(cand.dmax, 0x80, sizeof(int32_t) * npairs, s);   // below every distance
     hipLaunchKernelGGL(sift_query_tile_kernel<true>, dim3(nitems), dim3(kQueryWaves * 64), kLdsStream, s,
                        pairs, items, rr_y1, nullptr, nullptr, rule, cand, seg_counts);
 }
 
-void launch_sift_fused_finish(const SiftPair* pairs, int npairs, MatchRule rule, SiftCandidates cand,
+void launch_sift_fused_finish(const SiftPair* pairs, int npairs, int max_items, MatchRule rule, SiftCandidates cand,
                               const int32_t* seg_counts, hipStream_t s)
 {
-    hipLaunchKernelGGL(sift_rescan_kernel, dim3(kRescanGrid), dim3(kResolveWaves * 64), 0, s, pairs, rule, cand);
+    // (the rescan pass names candidates by their position in the strips' segments, which the gather pass then moves)
+    launch_sift_rescan(pairs, npairs, max_items, rule, cand, s);
     hipLaunchKernelGGL(sift_gather_segments_kernel, dim3(npairs), dim3(kStripRows), 0, s, pairs, seg_counts, cand);
 }
 
@@ -1100,14 +1276,14 @@ void launch_sift_verify_rows(const SiftPair* pairs, int npairs, int max_rows, co
     hipLaunchKernelGGL(sift_verify_rows_kernel<false>, grid, dim3(1024), 0, s, pairs, rr_y1, cand, slice_counts);
 }
 
-void launch_sift_resolve(const SiftPair* pairs, int npairs, int max_rows, MatchRule rule, SiftCandidates cand,
-                         hipStream_t s)
+void launch_sift_resolve(const SiftPair* pairs, int npairs, int max_rows, int max_items, MatchRule rule,
+                         SiftCandidates cand, hipStream_t s)
 {
     if (npairs <= 0) return;
     // enough waves per pair for its candidates (at most one per row), few enough blocks for short lists
     const int slices = std::max(1, std::min(64, (max_rows + 511) / 512));
     hipLaunchKernelGGL(sift_resolve_kernel, dim3(npairs * slices), dim3(kResolveWaves * 64), 0, s, pairs, slices, rule, cand);
-    hipLaunchKernelGGL(sift_rescan_kernel, dim3(kRescanGrid), dim3(kResolveWaves * 64), 0, s, pairs, rule, cand);
+    launch_sift_rescan(pairs, npairs, max_items, rule, cand, s);
 }
 
 // ---- 3. verify pass -------------------------------------------------------------------

@@ -107,7 +107,7 @@ struct vsm_ctx {
     std::string err;
     std::vector<DescSet> sets;
     // workspace (grow-only)
-    DevBuf d_pairs, d_rr1, d_rrj, d_rr2, d_colpart, d_cand;
+    DevBuf d_pairs, d_rr1, d_rrj, d_rr2, d_rr3, d_colpart, d_cand;
     DevBuf d_slot0, d_slot1, d_slotd, d_counts;
     DevBuf d_zero_tile;   // kTileBytes of zeros (see SiftCandidates::zero_tile)
     DevBuf d_dense0, d_dense1, d_knnj, d_knn1, d_knn2, d_stage, d_coarse, d_probs, d_geom, d_short;
@@ -116,6 +116,10 @@ struct vsm_ctx {
     int f32_reverse = VSM_F32_REVERSE_AUTO, last_f32_reverse = -1;
     // u8 sets: 0 = the tile-minimum query pass for ratio-test submissions (packed form otherwise), 1 = packed form only
     int u8_mode = 0, last_u8_path = -1;
+    // VSM_U8_AUTO only: after a tile-minimum submission most of whose rows needed the rescan pass (data full of
+    // exact duplicates), this many following submissions run the packed form before the tile-minimum form is tried again
+    int u8_packed_left = 0;
+    int last_u8_rescanned = -1;   // candidates of the last finished u8 submission that took the rescan pass
     int* flag_dev = nullptr;   // survivor-overflow flag of the last coarse submission (inside d_probs)
     HostBuf h_small, h_probs, h_gather;
     // Two sets of per-submission staging and result buffers, so that vsm_match_pairs can queue
@@ -130,6 +134,9 @@ struct vsm_ctx {
         hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
         bool ev_valid = false, ev_verify_valid = false;
         int query_pairs = 0;   // pairs in the launch the ev0..ev1 bracket belongs to
+        bool u8_stats = false;    // a u8 submission used this slot last: two counters of its rescan pass lie behind the offsets
+        bool tile_path = false;   // ... and it ran the tile-minimum query pass
+        size_t rows0 = 0;         // its image-0 rows over all pairs
     } slots[2];
     int rs = 0;   // slot the next submission uses / the last one used
     // submissions queued by vsm_submit_pairs and not yet collected (at most two, oldest first)
@@ -280,7 +287,8 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     // pass's items and their counter (written on the device)]: one copy command per submission
     const size_t pairs_bytes = (sizeof(SiftPair) * std::max(npairs, 1) + 255) & ~(size_t)255;
     HIPCHK(c, c->R().h_pairs.ensure(pairs_bytes + sizeof(SiftItem) * std::max(nitems, 1)));
-    HIPCHK(c, c->d_pairs.ensure(pairs_bytes + sizeof(SiftItem) * std::max(nitems + nvitems, 1) + 64));
+    // (after them, the rescan pass's items, at most as many as the query pass has)
+    HIPCHK(c, c->d_pairs.ensure(pairs_bytes + sizeof(SiftItem) * std::max(2 * nitems + nvitems, 1) + 64));
     const size_t rows = std::max<size_t>(pl.rows, 1);
     const size_t out0 = std::max<size_t>(pl.out0, 1), out1 = std::max<size_t>(pl.out1, 1);
     HIPCHK(c, c->d_rr1.ensure(rows * 4));
@@ -296,14 +304,23 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     }
     const int slice_ints = std::max(std::max(sift_select_slices(max_rows), sift_verify_rows_slices(max_rows)),
                                     kChunkCols / kStripRows);
-    HIPCHK(c, c->d_cand.ensure(out0 * 40 + sizeof(int32_t) * ((3 + (size_t)slice_ints) * std::max(npairs, 1) + 16)));
+    HIPCHK(c, c->d_cand.ensure(out0 * 40 + sizeof(int32_t) * ((4 + (size_t)slice_ints) * std::max(npairs, 1) + 16)));
     if (!c->d_zero_tile.p) {
         HIPCHK(c, c->d_zero_tile.ensure(kTileBytes));
         HIPCHK(c, hipMemsetAsync(c->d_zero_tile.p, 0, kTileBytes, c->stream));
     }
     // The tile-minimum query pass leaves row and exact distances to a resolve pass over the candidates: it
     // pays when the ratio test keeps the candidates few, and it does not produce the raw 2-NN outputs.
-    const bool tile_path = c->u8_mode != VSM_U8_PACKED && !o.packed_only && rule.num2 > 0 && !o.want_knn;
+    bool tile_path = c->u8_mode != VSM_U8_PACKED && !o.packed_only && rule.num2 > 0 && !o.want_knn;
+    if (tile_path && c->u8_mode == VSM_U8_AUTO && c->u8_packed_left > 0 && nitems > 0) {
+        // the last tile-minimum submission sent most of its rows to the rescan pass: the packed form is cheaper on such data
+        --c->u8_packed_left;
+        tile_path = false;
+    }
+    if (tile_path) HIPCHK(c, c->d_rr3.ensure(rows * 4));   // third array of the rescan pass's per-(chunk, slot) results
+    c->R().u8_stats = true;
+    c->R().tile_path = tile_path && nitems > 0;
+    c->R().rows0 = pl.out0;
     // select and resolve passes in the tail of the query pass: every pair at most one chunk of rows on either side
     // (a call with a pair or two is bound by its launches, and this form has one more of them)
     bool fused = tile_path && nitems > 0 && c->u8_mode != VSM_U8_TILE_SEPARATE &&
@@ -315,7 +332,9 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     HIPCHK(c, c->d_slot1.ensure(out0 * 4));
     if (o.want_dist) HIPCHK(c, c->d_slotd.ensure(out0 * 4));
     HIPCHK(c, c->d_counts.ensure(sizeof(int32_t) * std::max(npairs, 1)));
-    HIPCHK(c, c->R().d_offsets.ensure(sizeof(int64_t) * (npairs + 1)));
+    // (two more words behind the offsets: work items and candidates of the rescan pass, fetched with them)
+    HIPCHK(c, c->R().d_offsets.ensure(sizeof(int64_t) * (npairs + 2)));
+    int32_t* const d_stats = reinterpret_cast<int32_t*>(c->R().d_offsets.as<int64_t>() + npairs + 1);
     if (o.want_pack) {
         HIPCHK(c, c->R().d_tight0.ensure(out0 * 4));
         HIPCHK(c, c->R().d_tight1.ensure(out0 * 4));
@@ -368,14 +387,19 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
         cand.j1 = cand.i0 + out0;
         cand.d1 = cand.j1 + out0;
         cand.aux = cand.d1 + out0;
-        cand.rescan_list = reinterpret_cast<int2*>(cand.aux + out0);
-        int32_t* row_list = reinterpret_cast<int32_t*>(cand.rescan_list + out0);
+        cand.rescan_list = cand.aux + out0;
+        int32_t* row_list = cand.rescan_list + 2 * out0;
         int32_t* row_codes = row_list + out0;
         cand.count = row_codes + out0;
         int32_t* dmax = cand.count + std::max(npairs, 1);
         int32_t* nvrows = dmax + std::max(npairs, 1);
-        cand.rescan_count = nvrows + std::max(npairs, 1);
-        int32_t* slice_counts = cand.rescan_count + 16;
+        cand.rescan_cnt = nvrows + std::max(npairs, 1);
+        int32_t* slice_counts = cand.rescan_cnt + std::max(npairs, 1) + 16;
+        cand.rescan_items = d_items + nitems + nvitems + 8;   // behind the verify pass's items and their two counters
+        cand.rescan_nitems = d_stats;
+        cand.rs_d1 = c->d_rrj.as<int32_t>();   // the query pass's group and runner-up records are spent by then
+        cand.rs_j1 = c->d_rr2.as<int32_t>();
+        cand.rs_d2 = c->d_rr3.as<int32_t>();
         if (tile_path) {   // the packed path has no bound on the rows that matter: its verify pass streams them all
             cand.dmax = dmax;
             cand.vrows = row_list;
@@ -405,14 +429,14 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
                 HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
                 c->R().ev_valid = true;
             }
-            launch_sift_fused_finish(c->d_pairs.as<SiftPair>(), npairs, rule, cand, slice_counts, c->stream);
+            launch_sift_fused_finish(c->d_pairs.as<SiftPair>(), npairs, nitems, rule, cand, slice_counts, c->stream);
             if (nvitems)
                 launch_sift_verify_rows(c->d_pairs.as<SiftPair>(), npairs, max_rows, c->d_rr1.as<int32_t>(), cand,
                                         slice_counts, c->stream);
         } else if (tile_path) {
             launch_sift_select_tile(c->d_pairs.as<SiftPair>(), npairs, max_rows, max_chunks, c->d_rr1.as<int32_t>(),
                                     c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, slice_counts, c->stream);
-            launch_sift_resolve(c->d_pairs.as<SiftPair>(), npairs, max_rows, rule, cand, c->stream);
+            launch_sift_resolve(c->d_pairs.as<SiftPair>(), npairs, max_rows, nitems, rule, cand, c->stream);
             if (nvitems)
                 launch_sift_verify_rows(c->d_pairs.as<SiftPair>(), npairs, max_rows, c->d_rr1.as<int32_t>(), cand,
                                         slice_counts, c->stream);
@@ -420,6 +444,7 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
             launch_sift_select(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(),
                                c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, out, c->stream);
         }
+        if (!tile_path || nitems == 0) HIPCHK(c, hipMemsetAsync(d_stats, 0, 2 * sizeof(int32_t), c->stream));
         if (nvitems) {
             if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev2, c->stream));
             launch_sift_verify(c->d_pairs.as<SiftPair>(), npairs, d_items + nitems, nvitems,
@@ -435,8 +460,19 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
                         c->R().d_offsets.as<int64_t>(), c->d_slot0.as<int32_t>(), c->d_slot1.as<int32_t>(),
                         c->R().d_tight0.as<int32_t>(), c->R().d_tight1.as<int32_t>(), c->stream);
     }
+    else
+        HIPCHK(c, hipMemsetAsync(d_stats, 0, 2 * sizeof(int32_t), c->stream));
     HIPCHK(c, hipGetLastError());
     return VSM_OK;
+}
+
+// The rescan counters of the u8 submission that last used the current result slot, as fetched from behind its
+// offsets: kept for vsm_last_u8_rescanned, and (VSM_U8_AUTO) the next submissions go to the packed form when more than
+// one row in eight needed the rescan pass.
+void note_u8_stats(vsm_ctx* c, const int32_t* stats)
+{
+    c->last_u8_rescanned = stats[1];
+    if (c->R().tile_path && c->u8_mode == VSM_U8_AUTO && (size_t)stats[1] * 8 > c->R().rows0) c->u8_packed_left = 31;
 }
 
 MatchRule make_rule(const vsm_params* p)
@@ -537,7 +573,7 @@ extern "C" void vsm_destroy(vsm_ctx* c)
         if (s.nrm) (void)hipFree(s.nrm);
         if (s.shadow) (void)hipFree(s.shadow);
     }
-    DevBuf* bufs[] = {&c->d_zero_tile, &c->d_pairs, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_colpart, &c->d_cand,
+    DevBuf* bufs[] = {&c->d_zero_tile, &c->d_pairs, &c->d_rr1, &c->d_rrj, &c->d_rr2, &c->d_rr3, &c->d_colpart, &c->d_cand,
                       &c->d_slot0, &c->d_slot1, &c->d_slotd, &c->d_counts, &c->d_dense0, &c->d_dense1,
                       &c->d_knnj, &c->d_knn1, &c->d_knn2, &c->d_stage, &c->d_coarse,
                       &c->d_probs, &c->d_geom, &c->d_short};
@@ -728,10 +764,12 @@ extern "C" int vsm_set_u8_mode(vsm_ctx* c, int mode)
     if (!c) return VSM_EINVAL;
     if (mode < VSM_U8_AUTO || mode > VSM_U8_TILE_FUSED) return fail(c, VSM_EINVAL, "unknown u8 mode %d", mode);
     c->u8_mode = mode;
+    c->u8_packed_left = 0;   // what VSM_U8_AUTO learnt from earlier submissions is forgotten
     return VSM_OK;
 }
 
 extern "C" int vsm_last_u8_path(const vsm_ctx* c) { return c ? c->last_u8_path : VSM_EINVAL; }
+extern "C" int vsm_last_u8_rescanned(const vsm_ctx* c) { return c ? c->last_u8_rescanned : VSM_EINVAL; }
 
 extern "C" int vsm_release_set(vsm_ctx* c, int set)
 {
@@ -1037,6 +1075,7 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     // difference form afterwards, and the two orders need not agree on rows that were left out.
     const bool db_lists = two_phase && dot;
     c->R().ev_valid = false;
+    c->R().u8_stats = false;
     c->timing_slot = c->rs;
     c->last_f32_reverse = nrev == 0 ? -1 : two_phase ? VSM_F32_REVERSE_CANDIDATES : VSM_F32_REVERSE_ALL;
 
@@ -1274,6 +1313,7 @@ long long f32_pairs_slow(vsm_ctx* c, const int32_t* pairs, int npairs, const vsm
     }
     c->f32_mode = saved;
     const size_t tot = i0.size();
+    c->R().u8_stats = false;
     HIPCHK(c, c->R().d_offsets.ensure(sizeof(int64_t) * (npairs + 1)));
     HIPCHK(c, c->R().d_tight0.ensure(std::max<size_t>(tot, 1) * 4));
     HIPCHK(c, c->R().d_tight1.ensure(std::max<size_t>(tot, 1) * 4));
@@ -1320,10 +1360,13 @@ extern "C" long long vsm_match_pairs_device(vsm_ctx* c, const int32_t* pairs, in
     }
     HIPCHK(c, c->h_small.ensure(64));
     long long* tot = c->h_small.as<long long>();
-    *tot = 0;
+    tot[0] = tot[1] = 0;
+    const bool stats = !float_sets && c->R().u8_stats;
     if (npairs)
-        HIPCHK(c, hipMemcpyAsync(tot, c->R().d_offsets.as<int64_t>() + npairs, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(tot, c->R().d_offsets.as<int64_t>() + npairs, sizeof(int64_t) * (stats ? 2 : 1),
+                                 hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (stats) note_u8_stats(c, reinterpret_cast<const int32_t*>(tot + 1));
     c->last_npairs = npairs;
     c->last_total = *tot;
     c->last_slot = c->rs;
@@ -1477,10 +1520,12 @@ extern "C" long long vsm_collect_matches(vsm_ctx* c, int64_t* offsets, int32_t* 
     c->timing_slot = slot;
     vsm_ctx::ResultSlot& R = c->R();
     HIPCHK(c, hipEventSynchronize(R.packed));
-    HIPCHK(c, R.h_off.ensure(sizeof(int64_t) * (npairs + 1)));
-    HIPCHK(c, hipMemcpyAsync(R.h_off.p, R.d_offsets.p, sizeof(int64_t) * (npairs + 1), hipMemcpyDeviceToHost, c->copy_stream));
+    const bool stats = R.u8_stats && !c->inflight_on_host[slot];
+    HIPCHK(c, R.h_off.ensure(sizeof(int64_t) * (npairs + 2)));
+    HIPCHK(c, hipMemcpyAsync(R.h_off.p, R.d_offsets.p, sizeof(int64_t) * (npairs + (stats ? 2 : 1)), hipMemcpyDeviceToHost, c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     const int64_t* off = R.h_off.as<int64_t>();
+    if (stats) note_u8_stats(c, reinterpret_cast<const int32_t*>(off + npairs + 1));
     const long long got = off[npairs];
     c->last_npairs = npairs;
     c->last_total = got;
@@ -1548,10 +1593,13 @@ extern "C" int vsm_match_pair(vsm_ctx* c, int set0, int set1, const vsm_params* 
         ++seg.n;
     };
     int nm = 0;
+    int32_t stats[2] = {0, 0};
     add(c->d_counts.p, 1, &nm);
     if (idx0) add(c->d_slot0.p, take, idx0);
     if (idx1) add(c->d_slot1.p, take, idx1);
     if (dist) add(c->d_slotd.p, take, dist);
+    const int stats_seg = seg.n;
+    add(c->R().d_offsets.as<int64_t>() + 2, 2, stats);   // the rescan pass's counters (one pair: behind two offsets)
     size_t words = 0;
     for (int k = 0; k < seg.n; ++k) words += (size_t)seg.count[k];
     // the gather kernel writes straight into pinned host memory (it is mapped into the device's address space):
@@ -1563,10 +1611,11 @@ extern "C" int vsm_match_pair(vsm_ctx* c, int set0, int set1, const vsm_params* 
     const uint32_t* got = c->h_gather.as<uint32_t>();
     for (int k = 0; k < seg.n; ++k) {
         // the first segment is the count; list segments hold `take` slots of which nm are filled
-        const size_t fill = k == 0 ? 1 : (size_t)std::min(nm, take);
+        const size_t fill = k == 0 ? 1 : k == stats_seg ? 2 : (size_t)std::min(nm, take);
         memcpy(dst_host[k], got, fill * 4);
         got += seg.count[k];
     }
+    note_u8_stats(c, stats);
     if (nm > cap) return fail(c, VSM_ECAP, "%d matches do not fit a buffer of %d", nm, cap);
     return nm;
 }
@@ -1674,9 +1723,11 @@ extern "C" int vsm_match_pair_dense(vsm_ctx* c, int set0, int set1, const vsm_pa
     HIPCHK(c, c->h_small.ensure(64));
     int32_t* cnt = c->h_small.as<int32_t>();
     HIPCHK(c, hipMemcpyAsync(cnt, c->d_counts.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cnt + 2, c->R().d_offsets.as<int64_t>() + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     if (A->n) HIPCHK(c, hipMemcpyAsync(matches0, c->d_dense0.p, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
     if (B->n) HIPCHK(c, hipMemcpyAsync(matches1, c->d_dense1.p, sizeof(int32_t) * B->n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    note_u8_stats(c, cnt + 2);
     return *cnt;
 }
 

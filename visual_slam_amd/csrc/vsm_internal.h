@@ -79,13 +79,26 @@ struct SiftCandidates {
     // row (tile * 4 + lane quarter), d1 its half-distance y1, aux the smallest half-distance outside that group;
     // the resolve pass replaces j1 by the row (-1: rejected) and d1 by the exact squared distance.
     int32_t* aux;
-    int32_t* rescan_count;   // candidates the resolve pass could not settle from one group ...
-    int2* rescan_list;       // ... as (pair, candidate); the rescan pass searches the whole train set for them
+    // Candidates the resolve pass could not settle from one group (the minimum tied between groups, or the runner-up's
+    // parity bit deciding the ratio test): rescan_cnt[pair] of them, their positions in the pair's candidate list at
+    // rescan_list[out0_off + k] in no particular order.  The rescan pass gathers their rows of image 0, 512 per work
+    // item, and runs the packed form of the query pass over the whole train set for them; rescan_items (room for as
+    // many items as the query pass has) and rescan_nitems ([0] = items, [1] = candidates of the whole submission) are
+    // written on the device, rs_d1 / rs_j1 / rs_d2 hold its per-(chunk, list slot) results at
+    // row_off + chunk * nA_pad + slot.
+    int32_t* rescan_cnt;
+    int32_t* rescan_list;
+    SiftItem* rescan_items;
+    int32_t* rescan_nitems;
+    int32_t* rs_d1;
+    int32_t* rs_j1;
+    int32_t* rs_d2;
     // tile-minimum path only: the image-0 rows the verify pass has to look at.  dmax[pair] = the largest exact
     // distance of a candidate that passed its tests; a row whose own nearest distance (at least
     // 2 y1 + |a|^2) exceeds it is farther than that from EVERY train row, so it cannot come before any
     // candidate in any candidate's column.  vrows (at out0_off, ascending) lists the other rows, nvrows[pair]
-    // counts them.  NULL in the packed path: the verify pass then streams all of image 0.
+    // counts them.  NULL in the packed path and for rules without a ratio test or distance cap (every row is a
+    // candidate then and nothing bounds the rows that matter): the verify pass then streams all of image 0.
     int32_t* dmax;
     int32_t* vrows;
     int32_t* vcodes;   // per listed row: its squared norm << 8 | (position in the list & 255), the word the verify pass streams
@@ -210,18 +223,21 @@ int sift_verify_rows_slices(int max_rows);
 void launch_sift_query_tile_fused(const SiftPair* pairs, int npairs, const SiftItem* items, int nitems,
                                   int32_t* rr_y1, MatchRule rule, SiftCandidates cand, int32_t* seg_counts,
                                   hipStream_t s);
-void launch_sift_fused_finish(const SiftPair* pairs, int npairs, MatchRule rule, SiftCandidates cand,
+void launch_sift_fused_finish(const SiftPair* pairs, int npairs, int max_items, MatchRule rule, SiftCandidates cand,
                               const int32_t* seg_counts, hipStream_t s);
 void launch_sift_select_tile(const SiftPair* pairs, int npairs, int max_rows, int max_chunks, int32_t* rr_y1,
                              int32_t* rr_tile, int32_t* rr_k2, MatchRule rule, SiftCandidates cand,
                              int32_t* slice_counts, hipStream_t s);
+// The rescan pass over the candidates that launch_sift_resolve or the fused query pass left unsettled (see
+// SiftCandidates::rescan_cnt): plan, gathered packed query pass, merge of its chunks + exact tests.
+void launch_sift_rescan(const SiftPair* pairs, int npairs, int max_items, MatchRule rule, SiftCandidates cand, hipStream_t s);
 // After the resolve pass: cand.vrows / cand.nvrows from the merged half-distances the select pass left in
 // chunk 0's records of rr_y1.
 // slice_counts: sift_verify_rows_slices(max_rows) ints per pair of scratch.
 void launch_sift_verify_rows(const SiftPair* pairs, int npairs, int max_rows, const int32_t* rr_y1, SiftCandidates cand,
                              int32_t* slice_counts, hipStream_t s);
-void launch_sift_resolve(const SiftPair* pairs, int npairs, int max_rows, MatchRule rule, SiftCandidates cand,
-                         hipStream_t s);
+void launch_sift_resolve(const SiftPair* pairs, int npairs, int max_rows, int max_items, MatchRule rule,
+                         SiftCandidates cand, hipStream_t s);
 // chunk merge + distance/ratio tests -> candidate lists (+ raw 2-NN outputs)
 void launch_sift_select(const SiftPair* pairs, int npairs, const int32_t* rr_d1, const int32_t* rr_j1,
                         const int32_t* rr_d2, MatchRule rule, SiftCandidates cand, SiftOutputs out,
