@@ -683,6 +683,7 @@ def run_shortlist(args, torch, dist, world, rank):
     m = vsm.Matcher(torch.cuda.current_device())
     ids = [m.upload_u8_device(arena[i].data_ptr(), nfeat) for i in range(nimg)]
     vid = m.upload_u8_device(vocab.data_ptr(), nwords)
+    m.set_u8_mode(args.u8_mode)
     m.set_timing(True)
     for _ in range(args.warmup):
         m.shortlist_pairs(ids, vid, topk)

@@ -106,16 +106,20 @@ int vsm_set_f32_reverse(vsm_ctx* ctx, int mode);
 int vsm_last_f32_reverse(const vsm_ctx* ctx);
 /* How u8 (SIFT) sets are searched.  Both forms return the same bits (exact integer distances, lowest
  * index on ties).
- *   VSM_U8_AUTO (default): submissions with a ratio test run the tile-minimum query pass (the matrix
- *     cores produce half-distances directly, each lane keeps the minimum per 32-row tile) and settle row,
- *     exact distance and tests for the few candidates afterwards; their mutual check looks only at the
- *     image-0 rows near enough to anything to matter.  Everything else (no ratio test, raw 2-NN) runs the
- *     packed form.
+ *   VSM_U8_AUTO (default): pair submissions run the tile-minimum query pass (the matrix cores produce
+ *     half-distances directly, each lane keeps the minimum per 32-row tile) and settle row, exact distance and tests
+ *     for the candidates afterwards, from the 8-row group that holds the minimum (every row is a candidate when the
+ *     rule has neither a ratio test nor a distance cap); rows that group cannot settle (ties between groups) take a
+ *     rescan pass, see vsm_last_u8_rescanned.  With a ratio test or cap the mutual check looks only at the image-0
+ *     rows near enough to anything to matter.  The raw 2-NN call (vsm_knn2) runs the packed form: the tile-minimum
+ *     pass knows the runner-up distance only up to ties.
  *     In a submission of eight pairs or more whose sets all have at most 8192 rows, the settling of a strip of 512
  *     query rows runs in the tail of the query kernel itself, while the train image is still in the cache.
  *   VSM_U8_PACKED: the packed form only (value and row in one key for every distance).
  *   VSM_U8_TILE_SEPARATE / VSM_U8_TILE_FUSED: as VSM_U8_AUTO, with the settling always in passes of its own /
- *     in the query kernel's tail whenever the sets' sizes allow it, whatever the number of pairs. */
+ *     in the query kernel's tail whenever the sets' sizes allow it, whatever the number of pairs, and without
+ *     VSM_U8_AUTO's change to the packed form on data full of duplicates.
+ * Setting a mode also makes VSM_U8_AUTO forget what it learnt from earlier submissions. */
 enum { VSM_U8_AUTO = 0, VSM_U8_PACKED = 1, VSM_U8_TILE_SEPARATE = 2, VSM_U8_TILE_FUSED = 3 };
 int vsm_set_u8_mode(vsm_ctx* ctx, int mode);
 /* Which query pass the last u8 submission ran: 0 = tile-minimum, 1 = packed, 2 = tile-minimum with the candidates
@@ -150,8 +154,9 @@ int vsm_match_pair_dense(vsm_ctx* ctx, int set0, int set1, const vsm_params* p, 
  * results go straight to the caller's DEVICE buffers: idx0_dev / idx1_dev (cap >= rows of set0 entries
  * each; the first *count_dev are valid) and count_dev (one int32).  The work is queued on the context's
  * stream (vsm_stream) and the call returns without waiting; VSM_ECAP when a set has more than 16384
- * rows.  Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two
- * contexts, two streams) race; calls on one context are ordered by its stream. */
+ * rows.  Every call on a GPU shares that GPU's array: the library orders them behind one another with an
+ * event per device (a call waits on the device for the one queued before it, whatever context or stream
+ * that came from), so calls from several contexts do not corrupt each other, and do not overlap either. */
 int vsm_match_pair_noalloc(vsm_ctx* ctx, int set0, int set1, const vsm_params* p,
                            int32_t* idx0_dev, int32_t* idx1_dev, int32_t* count_dev, int cap);
 /* Many pairs in one submission (the per-pair loop of main.py:220-280).  pairs is

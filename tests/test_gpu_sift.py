@@ -258,9 +258,9 @@ def test_tile_minimum_path_is_the_one_that_runs(matcher, u8_mode):
         matcher.match_pair(s0, s1, ratio=0.8, mutual=True)
         assert matcher.last_u8_path() == {0: 0, 1: 1, 3: 2}[u8_mode]   # 0: tile-minimum, 1: packed, 2: tile-minimum with the tail
         matcher.match_pair(s0, s1, ratio=None, mutual=True)
-        assert matcher.last_u8_path() == 1                # no ratio test: packed form in either mode
+        assert matcher.last_u8_path() == {0: 0, 1: 1, 3: 2}[u8_mode]   # no ratio test: every row is resolved from its group
         matcher.knn2(s0, s1)
-        assert matcher.last_u8_path() == 1
+        assert matcher.last_u8_path() == 1                # raw 2-NN: the packed form in every mode
     finally:
         matcher.release(s0)
         matcher.release(s1)

@@ -1,11 +1,13 @@
 """vsm_match_pair_noalloc (the entry point that allocates nothing) against vsm_match_pair on the same
-resident sets: same lists, bit for bit, on calls in a row that share the per-GPU scratch array, a
-smaller pair after a larger one included."""
+resident sets and against the CPU oracle: same lists, bit for bit, on calls in a row that share the per-GPU
+scratch array, a smaller pair after a larger one included; and the device's free memory does not move
+across a hundred calls."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
+import oracle_lib as orc
 import visual_slam_amd as vsm
 from visual_slam_amd import synth
 
@@ -60,12 +62,53 @@ def test_noalloc_equals_match_pair_on_calls_in_a_row(matcher):
                     g0, g1 = _run(matcher, out, s0, s1, n0, **kw)
                     np.testing.assert_array_equal(g0, w0)
                     np.testing.assert_array_equal(g1, w1)
+                    o0, o1, _ = orc.match_u8(a, b, orc.params((4, 5) if kw["ratio"] else None, kw["mutual"]))
+                    np.testing.assert_array_equal(g0, o0)
+                    np.testing.assert_array_equal(g1, o1)
                 if n0 >= 700:
                     assert len(w0) > 0
             finally:
                 matcher.release(s0)
                 matcher.release(s1)
     finally:
+        out.free()
+
+
+def _free_bytes(hip):
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_noalloc_leaves_the_free_memory_where_it_was(matcher):
+    """A hundred calls, shapes and rules changing from call to call (every row of the duplicate sets takes the rescan
+    pass): the free device memory reads the same before and after, and the last lists equal the oracle's."""
+    rng = np.random.default_rng(5)
+    out = DevOut(4096)
+    a, b = synth.sift_pair(4096, 3000, seed=77)
+    dup = np.ascontiguousarray(synth.sift_like(30, rng)[rng.integers(0, 30, 2500)])
+    ids = [matcher.upload_u8(x) for x in (a, b, dup)]
+    sizes = {ids[0]: 4096, ids[1]: 3000, ids[2]: 2500}
+    try:
+        _run(matcher, out, ids[0], ids[1], 4096)          # first call on this process's context: kernels get loaded
+        before = _free_bytes(out.hip)
+        for k in range(100):
+            s0, s1 = [(ids[0], ids[1]), (ids[1], ids[0]), (ids[2], ids[2]), (ids[2], ids[0])][k % 4]
+            matcher.match_pair_noalloc(s0, s1, out.ptrs[0].value, out.ptrs[1].value, out.ptrs[2].value, sizes[s0],
+                                       ratio=(0.8 if k % 3 else None), mutual=bool(k % 2))
+        matcher.synchronize()
+        assert _free_bytes(out.hip) == before
+        g0, g1 = _run(matcher, out, ids[2], ids[0], 2500)
+        o0, o1, _ = orc.match_u8(dup, a, orc.params((4, 5), True))
+        np.testing.assert_array_equal(g0, o0)
+        np.testing.assert_array_equal(g1, o1)
+        g0, g1 = _run(matcher, out, ids[2], ids[2], 2500, ratio=None, mutual=False)
+        o0, o1, _ = orc.match_u8(dup, dup, orc.params(None, False))
+        np.testing.assert_array_equal(g0, o0)
+        np.testing.assert_array_equal(g1, o1)
+    finally:
+        for sid in ids:
+            matcher.release(sid)
         out.free()
 
 

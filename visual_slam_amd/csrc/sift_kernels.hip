@@ -587,30 +587,48 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
         const int8_t VSM_GLB* fragB = (const int8_t VSM_GLB*)pw.fragB;
         const int32_t VSM_GLB* nrmB = (const int32_t VSM_GLB*)pw.nrmB;
         const int seg0 = it.strip * kStripRows;
-        for (int c0c = wave * 8; c0c < total; c0c += kQueryWaves * 8) {
-            const int c = c0c + grp;
-            const bool have = c < total;
-            const int cc = have ? c : c0c;
+        // Eight lanes per candidate, as in sift_resolve_kernel.  Two batches of eight candidates per wave are in flight:
+        // the loads of both are issued before either is reduced (with every row of a strip a candidate -- rules
+        // without a test -- the tail otherwise waits for one round trip to memory per batch, sixteen in a row).
+        struct Batch {
+            int c, i, g, y1, y2, nrmb;
+            bool have;
+            long long na;
+            v4i q[8], t[8];
+        };
+        auto issue = [&](int c0c, Batch& b) {
+            b.c = c0c + grp;
+            b.have = b.c < total;
+            const int cc = b.have ? b.c : wave * 8;   // (a candidate that exists: wave * 8 < total whenever the loop runs)
             int v = 0;
 #pragma unroll
             for (int u = 1; u < kQueryWaves; ++u) v += cc >= pre[u] ? 1 : 0;
             const int4 rec = s_cand[v * 128 + (cc - pre[v])];
-            const int i = rec.x, g = rec.y, y1 = rec.z, y2 = rec.w;
-            const long long na = pw.nrmA[i] >> 8;
-            const int tl = g >> 2, qd = g & 3;
+            b.i = rec.x; b.g = rec.y; b.y1 = rec.z; b.y2 = rec.w;
+            const int tl = b.g >> 2, qd = b.g & 3;
             const int r = (k8 >> 2) * 16 + qd * 4 + (k8 & 3);     // row of the tile
-            const int8_t VSM_GLB* q = fragA + (size_t)(i >> 5) * kTileBytes + (i & 31) * 16;
+            const int8_t VSM_GLB* q = fragA + (size_t)(b.i >> 5) * kTileBytes + (b.i & 31) * 16;
             const int8_t VSM_GLB* t = fragB + (size_t)tl * kTileBytes + r * 16;
-            int dot = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    dot = dot16(*reinterpret_cast<const v4i VSM_GLB*>(q + s * 1024 + h * 512),
-                                *reinterpret_cast<const v4i VSM_GLB*>(t + s * 1024 + h * 512), dot);
+                for (int h = 0; h < 2; ++h) {
+                    b.q[2 * s + h] = *reinterpret_cast<const v4i VSM_GLB*>(q + s * 1024 + h * 512);
+                    b.t[2 * s + h] = *reinterpret_cast<const v4i VSM_GLB*>(t + s * 1024 + h * 512);
+                }
             }
             const int row = tl * 32 + r;
-            const int key = row < pw.nB ? ((nrmB[row] >> 8) - 2 * dot) * 8 + k8 : INT32_MAX;
+            b.nrmb = row < pw.nB ? nrmB[row] >> 8 : INT32_MAX;
+            b.na = pw.nrmA[b.i] >> 8;
+        };
+        auto settle = [&](const Batch& b) {
+            const int i = b.i, y1 = b.y1, y2 = b.y2;
+            const long long na = b.na;
+            const int tl = b.g >> 2, qd = b.g & 3;
+            int dot = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dot = dot16(b.q[u], b.t[u], dot);
+            const int key = b.nrmb != INT32_MAX ? (b.nrmb - 2 * dot) * 8 + k8 : INT32_MAX;
             const int best = group8_min(key);
             const int second = group8_min(k8 == (best & 7) ? INT32_MAX : key);
             const int kb = best & 7, x1 = best >> 3;
@@ -630,8 +648,8 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
                 }
                 pass = pr && (rule.max_dist < 0 || d1 <= rule.max_dist);
             }
-            if (have && k8 == 0) {
-                const int cpos = seg0 + c;
+            if (b.have && k8 == 0) {
+                const int cpos = seg0 + b.c;
                 const size_t o = pw.out0_off + cpos;
                 cand.i0[o] = i;
                 cand.vbest[o] = ~0ull;
@@ -646,6 +664,13 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
                     if (pass && cand.dmax) atomicMax(&cand.dmax[it.pair], (int)d1);
                 }
             }
+        };
+        for (int c0c = wave * 8; c0c < total; c0c += 2 * kQueryWaves * 8) {
+            Batch b0, b1;
+            issue(c0c, b0);
+            issue(c0c + kQueryWaves * 8, b1);
+            settle(b0);
+            settle(b1);
         }
         if (tid == 0) seg_counts[it.pair * (kChunkCols / kStripRows) + it.strip] = total;
     }

@@ -27,6 +27,9 @@ constexpr int kMaxDevices = 256;
 static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
 static std::mutex g_scratch_mu;
 static void* g_scratch_ptr[kMaxDevices] = {};
+// recorded behind every vsm_match_pair_noalloc call on the device and waited for by the next one: calls that share
+// the array run one after the other even when they come from different contexts
+static hipEvent_t g_scratch_done[kMaxDevices] = {};
 
 namespace {
 
@@ -100,6 +103,7 @@ struct vsm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     unsigned char* noalloc_scratch = nullptr;   // this device's copy of `scratch`
+    hipEvent_t noalloc_done = nullptr;          // this device's g_scratch_done
     // Workgroups a float search is cut into when its database is long enough: two per CU, i.e. the coarse grid
     // is resident all at once (512 on a whole MI355X; twice as many ran 2.5 % slower on the 16384 x 1M query:
     // half as long survivor sublists, whose thresholds are young for a larger share of their tiles)
@@ -309,9 +313,12 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
         HIPCHK(c, c->d_zero_tile.ensure(kTileBytes));
         HIPCHK(c, hipMemsetAsync(c->d_zero_tile.p, 0, kTileBytes, c->stream));
     }
-    // The tile-minimum query pass leaves row and exact distances to a resolve pass over the candidates: it
-    // pays when the ratio test keeps the candidates few, and it does not produce the raw 2-NN outputs.
-    bool tile_path = c->u8_mode != VSM_U8_PACKED && !o.packed_only && rule.num2 > 0 && !o.want_knn;
+    // The tile-minimum query pass leaves row and exact distances to a resolve pass over the candidates (every row
+    // when the rule has no test that thins them out: nearest row only, e.g. the word of every descriptor); it does
+    // not produce the raw 2-NN outputs, whose runner-up distance it knows only up to a tie.
+    bool tile_path = c->u8_mode != VSM_U8_PACKED && !o.packed_only && !o.want_knn;
+    // a bound on the image-0 rows the mutual check must look at exists only when a test keeps the candidates near
+    const bool row_lists = rule.num2 > 0 || rule.max_dist >= 0;
     if (tile_path && c->u8_mode == VSM_U8_AUTO && c->u8_packed_left > 0 && nitems > 0) {
         // the last tile-minimum submission sent most of its rows to the rescan pass: the packed form is cheaper on such data
         --c->u8_packed_left;
@@ -400,7 +407,7 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
         cand.rs_d1 = c->d_rrj.as<int32_t>();   // the query pass's group and runner-up records are spent by then
         cand.rs_j1 = c->d_rr2.as<int32_t>();
         cand.rs_d2 = c->d_rr3.as<int32_t>();
-        if (tile_path) {   // the packed path has no bound on the rows that matter: its verify pass streams them all
+        if (tile_path && row_lists) {   // otherwise nothing bounds the rows that matter: the verify pass streams them all
             cand.dmax = dmax;
             cand.vrows = row_list;
             cand.vcodes = row_codes;
@@ -430,14 +437,14 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
                 c->R().ev_valid = true;
             }
             launch_sift_fused_finish(c->d_pairs.as<SiftPair>(), npairs, nitems, rule, cand, slice_counts, c->stream);
-            if (nvitems)
+            if (nvitems && row_lists)
                 launch_sift_verify_rows(c->d_pairs.as<SiftPair>(), npairs, max_rows, c->d_rr1.as<int32_t>(), cand,
                                         slice_counts, c->stream);
         } else if (tile_path) {
             launch_sift_select_tile(c->d_pairs.as<SiftPair>(), npairs, max_rows, max_chunks, c->d_rr1.as<int32_t>(),
                                     c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, slice_counts, c->stream);
             launch_sift_resolve(c->d_pairs.as<SiftPair>(), npairs, max_rows, nitems, rule, cand, c->stream);
-            if (nvitems)
+            if (nvitems && row_lists)
                 launch_sift_verify_rows(c->d_pairs.as<SiftPair>(), npairs, max_rows, c->d_rr1.as<int32_t>(), cand,
                                         slice_counts, c->stream);
         } else {
@@ -537,13 +544,20 @@ extern "C" vsm_ctx* vsm_create(int device)
                 fail(nullptr, VSM_ENODEV, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e));
                 return nullptr;
             }
+            hipEvent_t ev = nullptr;
+            if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) {
+                fail(nullptr, VSM_ENODEV, "hipEventCreate on device %d: %s", device, hipGetErrorString(e));
+                return nullptr;
+            }
             g_scratch_ptr[device] = ptr;
+            g_scratch_done[device] = ev;
         }
         scratch_dev = static_cast<unsigned char*>(g_scratch_ptr[device]);
     }
     vsm_ctx* c = new vsm_ctx();
     c->device = device;
     c->noalloc_scratch = scratch_dev;
+    c->noalloc_done = device < kMaxDevices ? g_scratch_done[device] : nullptr;
     c->coarse_wgs = std::max(2 * prop.multiProcessorCount, 64);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->slots[0].ev0)) != hipSuccess || (e = hipEventCreate(&c->slots[0].ev1)) != hipSuccess ||
@@ -1620,10 +1634,11 @@ extern "C" int vsm_match_pair(vsm_ctx* c, int set0, int set1, const vsm_params* 
     return nm;
 }
 
-// One u8 pair through the same kernels as vsm_match_pair, with every intermediate in the per-device
-// static scratch array and the results written straight into the caller's device buffers.  Calls no
-// hipMalloc / hipFree / allocating routine: the pair record travels as a kernel argument and the work
-// items are written by a kernel.
+// One u8 pair through the same kernels as vsm_match_pair (the tile-minimum form with its passes one after the other),
+// with every intermediate in the per-device static scratch array and the results written straight into the caller's
+// device buffers.  Calls no hipMalloc / hipFree / allocating routine: the pair record travels as a kernel argument
+// and the work items are written by a kernel.  Calls on one GPU are ordered behind one another by an event per
+// device (created in vsm_create), whatever context or stream they come from: they share the array.
 extern "C" int vsm_match_pair_noalloc(vsm_ctx* c, int set0, int set1, const vsm_params* p,
                                       int32_t* idx0_dev, int32_t* idx1_dev, int32_t* count_dev, int cap)
 {
@@ -1640,7 +1655,7 @@ extern "C" int vsm_match_pair_noalloc(vsm_ctx* c, int set0, int set1, const vsm_
         return fail(c, VSM_ECAP, "vsm_match_pair_noalloc takes sets of at most %d rows (got %d and %d): its scratch is a fixed "
                                  "%zu-byte array", kNoAllocMaxRows, A->n, B->n, kNoAllocScratchBytes);
     if (cap < A->n) return fail(c, VSM_ECAP, "idx0_dev / idx1_dev must hold %d entries (one per image-0 row), cap is %d", A->n, cap);
-    if (!c->noalloc_scratch) return fail(c, VSM_EUNSUPPORTED, "no scratch array on device %d", c->device);
+    if (!c->noalloc_scratch || !c->noalloc_done) return fail(c, VSM_EUNSUPPORTED, "no scratch array on device %d", c->device);
     HIPCHK(c, hipSetDevice(c->device));
     if (A->n == 0 || B->n == 0) {
         HIPCHK(c, hipMemsetAsync(count_dev, 0, sizeof(int32_t), c->stream));
@@ -1658,6 +1673,8 @@ extern "C" int vsm_match_pair_noalloc(vsm_ctx* c, int set0, int set1, const vsm_
     const int nitems = sp.nstrips * sp.nchunks;
     const int nvitems = p->mutual ? (A->n + kVerifyBlock - 1) / kVerifyBlock : 0;
     const size_t rows = (size_t)sp.nchunks * sp.nA_pad, out0 = (size_t)A->n;
+    const MatchRule rule = make_rule(p);
+    const bool row_lists = rule.num2 > 0 || rule.max_dist >= 0;
     // carve the scratch array (every part 256-byte aligned)
     size_t off = 0;
     auto carve = [&](size_t bytes) {
@@ -1665,33 +1682,62 @@ extern "C" int vsm_match_pair_noalloc(vsm_ctx* c, int set0, int set1, const vsm_
         off += (bytes + 255) & ~(size_t)255;
         return c->noalloc_scratch + at;
     };
+    int8_t* zero_tile = reinterpret_cast<int8_t*>(carve(kTileBytes));
     SiftPair* d_pair = reinterpret_cast<SiftPair*>(carve(sizeof(SiftPair)));
-    SiftItem* d_items = reinterpret_cast<SiftItem*>(carve(sizeof(SiftItem) * (size_t)(nitems + nvitems) + 64));
+    // query items, the verify pass's items and their two counters, then the rescan pass's items
+    SiftItem* d_items = reinterpret_cast<SiftItem*>(carve(sizeof(SiftItem) * (size_t)(2 * nitems + nvitems + 8)));
     int32_t* rr1 = reinterpret_cast<int32_t*>(carve(rows * 4));
     int32_t* rrj = reinterpret_cast<int32_t*>(carve(rows * 4));
     int32_t* rr2 = reinterpret_cast<int32_t*>(carve(rows * 4));
     SiftCandidates cand{};
+    cand.rs_d1 = rrj;   // the group and runner-up records are spent when the rescan pass runs
+    cand.rs_j1 = rr2;
+    cand.rs_d2 = reinterpret_cast<int32_t*>(carve(rows * 4));
     cand.vbest = reinterpret_cast<unsigned long long*>(carve(out0 * 8));
     cand.i0 = reinterpret_cast<int32_t*>(carve(out0 * 4));
     cand.j1 = reinterpret_cast<int32_t*>(carve(out0 * 4));
     cand.d1 = reinterpret_cast<int32_t*>(carve(out0 * 4));
-    cand.count = reinterpret_cast<int32_t*>(carve(sizeof(int32_t)));
+    cand.aux = reinterpret_cast<int32_t*>(carve(out0 * 4));
+    cand.rescan_list = reinterpret_cast<int32_t*>(carve(out0 * 4));
+    int32_t* row_list = reinterpret_cast<int32_t*>(carve(out0 * 4));
+    int32_t* row_codes = reinterpret_cast<int32_t*>(carve(out0 * 4));
+    // count, largest accepted distance, row-list length, rescan count, the rescan pass's two counters, slice counts
+    int32_t* small = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * (8 + 2 * kMaxRowSlices)));
+    cand.count = small;
+    cand.rescan_cnt = small + 3;
+    cand.rescan_nitems = small + 4;
+    int32_t* slice_counts = small + 8;
+    cand.rescan_items = d_items + nitems + nvitems + 8;
+    if (row_lists) {
+        cand.dmax = small + 1;
+        cand.nvrows = small + 2;
+        cand.vrows = row_list;
+        cand.vcodes = row_codes;
+        cand.zero_tile = zero_tile;
+    }
     if (off > kNoAllocScratchBytes)
         return fail(c, VSM_ECAP, "this pair needs %zu bytes of scratch, the fixed array holds %zu", off, kNoAllocScratchBytes);
-    // Everything a kernel of this call reads from the scratch array is written earlier in the same call
-    // (pair record and items by the plan kernel, partial results by the query pass for every padded row,
-    // candidate records and their count by the select pass, the verify item list by its plan kernel), so
-    // the contents an earlier call left behind are never read and nothing needs clearing.
+    // Everything a kernel of this call reads from the scratch array is written earlier in the same call (pair record
+    // and items by the plan kernel, partial results by the query pass for every padded row, candidate records, counts
+    // and the largest accepted distance by the select and resolve passes, the rescan and verify item lists by their
+    // plan kernels), except the tile of zeros, which is cleared here: what an earlier call left behind is never read.
+    std::lock_guard<std::mutex> lock(g_scratch_mu);   // the wait and the record below are one step for other threads
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->noalloc_done, 0));
+    HIPCHK(c, hipMemsetAsync(zero_tile, 0, kTileBytes, c->stream));
     launch_sift_plan_single(sp, d_pair, d_items, c->stream);
-    launch_sift_query(d_pair, d_items, nitems, rr1, rrj, rr2, p->ratio_num > 0, c->stream);
+    launch_sift_query_tile(d_pair, d_items, nitems, rr1, rrj, rr2, c->stream);
+    launch_sift_select_tile(d_pair, 1, A->n, sp.nchunks, rr1, rrj, rr2, rule, cand, slice_counts, c->stream);
+    launch_sift_resolve(d_pair, 1, A->n, nitems, rule, cand, c->stream);
     SiftOutputs out{};
     out.slot_i0 = idx0_dev;
     out.slot_i1 = idx1_dev;
     out.counts = count_dev;
-    launch_sift_select(d_pair, 1, rr1, rrj, rr2, make_rule(p), cand, out, c->stream);
-    if (nvitems)
+    if (nvitems) {
+        if (row_lists) launch_sift_verify_rows(d_pair, 1, A->n, rr1, cand, slice_counts, c->stream);
         launch_sift_verify(d_pair, 1, d_items + nitems, nvitems, reinterpret_cast<int*>(d_items + nitems + nvitems), cand, c->stream);
+    }
     launch_sift_confirm(d_pair, 1, cand, nvitems ? 1 : 0, out, c->stream);
+    HIPCHK(c, hipEventRecord(c->noalloc_done, c->stream));
     HIPCHK(c, hipGetLastError());
     return VSM_OK;
 }
