@@ -209,6 +209,25 @@ int vsm_merge_top2_f32(const float* k1, const float* k2, const int32_t* i1, cons
 int vsm_knn2_device(vsm_ctx* ctx, int set_q, int set_db, int metric, void* packed_dev);
 int vsm_merge_top2_device(vsm_ctx* ctx, const void* packed_dev, const int64_t* base, int nslices, int nq,
                           int metric, float* ok1, float* ok2, int64_t* oi1, int64_t* oi2);
+/* A database sliced over the GPUs of this machine, in one process (the multi-GPU form of the same brute-force
+ * search; the reference searches its 512 codes on one device, model_2_0.py:43-78).  devices[ndev] are distinct HIP
+ * devices; the database rows are cut into nslices contiguous ranges of (nearly) equal size, nslices a multiple of
+ * ndev, device d holding slices d * nslices / ndev ... (a context of its own per device, created here).
+ * vsm_dbq_load uploads the rows (any earlier database is dropped).  vsm_dbq_query uploads the queries to every
+ * device, searches every slice (vsm_knn2_device), brings the per-slice lists together with an RCCL all-gather over
+ * the devices (librccl is loaded when the first handle is created; VSM_ENODEV when it is not installed) and merges
+ * them on the first device (vsm_merge_top2_device): k1 / k2 / i1 / i2 [nq] are keys and global rows of the nearest
+ * row and the runner-up, as vsm_knn2 over the whole database returns them (-1 when the database has fewer rows).
+ * Returns nq or a negative code; vsm_dbq_last_error(NULL) describes a failed create.  A handle is single-threaded. */
+typedef struct vsm_dbq vsm_dbq;
+vsm_dbq* vsm_dbq_create(const int* devices, int ndev, int nslices);
+void vsm_dbq_destroy(vsm_dbq* q);
+const char* vsm_dbq_last_error(const vsm_dbq* q);
+int vsm_dbq_load(vsm_dbq* q, const float* rows, long long n, int dim, int layout);
+/* Number of slices; base[nslices + 1] (may be NULL) receives the first database row of every slice. */
+int vsm_dbq_slices(const vsm_dbq* q, int64_t* base);
+int vsm_dbq_query(vsm_dbq* q, const float* queries, int nq, int layout, int metric,
+                  float* k1, float* k2, int64_t* i1, int64_t* i2);
 /* NearestEmbedFunc.forward (model_2_0.py:43-78): x [batch][dim][npts], emb [dim][k];
  * argmin [batch][npts] int64, result (may be NULL) [batch][dim][npts]. */
 int vsm_nearest_embed(vsm_ctx* ctx, const float* x, int batch, int dim, int npts,

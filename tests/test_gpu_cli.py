@@ -245,3 +245,42 @@ def test_cli_explicit_pair_list(tmp_path):
         res = subprocess.run([CLI, "--sift-dir", str(tmp_path), "--num", "5", "--out", out, "--pairs-file", str(lst)],
                              capture_output=True, text=True, timeout=120)
         assert res.returncode == 1, bad
+
+
+def test_several_contexts_in_one_process_write_the_single_context_files(tmp_path):
+    """--devices: a thread and a context per entry take the submissions as they come, one writer thread emits them in
+    pair order: match txt, inlier txt and every .mat record (putative, inlier and pose) are byte for byte those of
+    the run with one context.  Here both contexts sit on GPU 0."""
+    nimg, n = 6, 400
+    kps, dess = synth.multi_view(nimg, n, seed=41)
+    for i in range(nimg):
+        loc = np.zeros((n, 5), np.float32)
+        loc[:, :2] = kps[i]
+        loc[:, 3] = 1.0
+        host.write_sift(str(tmp_path / ("%d.sift" % i)), loc, dess[i])
+
+    def run(devices, batch):
+        for i in range(nimg):
+            mat = tmp_path / ("%d.mat" % i)
+            if mat.exists():
+                mat.unlink()
+        out, inl = str(tmp_path / "matching.txt"), str(tmp_path / "inliers.txt")
+        cmd = [CLI, "--sift-dir", str(tmp_path), "--num", str(nimg), "--out", out, "--batch", str(batch), "--mat",
+               "--verify", "1.5", "--samples", "200", "--seed", "9", "--inlier-out", inl, "--camera", "1200,1200,800,600",
+               "--devices", devices]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+        assert res.returncode == 0, res.stderr
+        files = {"matching": open(out, "rb").read(), "inliers": open(inl, "rb").read()}
+        for i in range(nimg):
+            files["%d.mat" % i] = open(str(tmp_path / ("%d.mat" % i)), "rb").read()
+        return files, res.stderr
+
+    one, log1 = run("0", 4)
+    two, log2 = run("0,0", 2)          # eight submissions dealt to two contexts
+    three, _ = run("0,0,0", 1)
+    assert "on 1 context;" in log1 and "on 2 contexts;" in log2
+    assert set(one) == set(two) == set(three)
+    for name in one:
+        assert one[name] == two[name], name
+        assert one[name] == three[name], name
+    assert len(one["matching"]) > 5000 and len(one["0.mat"]) > 5000

@@ -9,6 +9,7 @@ without a gfx950 device every compute call raises.
 from ._binding import (  # noqa: F401
     VsmError,
     Matcher,
+    SlicedDatabase,
     lib,
     lib_path,
     METRIC_DOT,
@@ -55,7 +56,7 @@ from .host import (  # noqa: F401
 )
 
 __all__ = [
-    "VsmError", "Matcher", "lib", "lib_path",
+    "VsmError", "Matcher", "SlicedDatabase", "lib", "lib_path",
     "METRIC_DOT", "METRIC_L2", "LAYOUT_ROWS", "LAYOUT_DIM_MAJOR", "NO_SECOND",
     "F32_FAST_EXACT", "F32_MFMA_F32", "F32_REVERSE_AUTO", "F32_REVERSE_CANDIDATES", "F32_REVERSE_ALL", "U8_AUTO", "U8_PACKED", "U8_TILE_SEPARATE", "U8_TILE_FUSED",
     "generate_imagePairs", "generate_exhaustive_pairs", "get_list_matching_pairs",

@@ -85,6 +85,13 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsm_merge_top2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsm_dbq_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    "vsm_dbq_destroy": (None, [C.c_void_p]),
+    "vsm_dbq_last_error": (C.c_char_p, [C.c_void_p]),
+    "vsm_dbq_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int]),
+    "vsm_dbq_slices": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vsm_dbq_query": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p]),
     "vsm_nearest_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_void_p]),
     "vsm_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
@@ -517,3 +524,57 @@ def merge_top2_f32(k1, k2, i1, i2, base, metric):
     if rc < 0:
         raise VsmError(rc, "vsm_merge_top2_f32")
     return ok1, ok2, oi1, oi2
+
+
+class SlicedDatabase:
+    """A float database cut into slices over the GPUs of this machine (vsm_dbq_*): every query's two nearest rows
+    over the whole database, the per-slice lists merged after an RCCL all-gather."""
+
+    def __init__(self, devices=(0,), nslices=None):
+        self._l = lib()
+        devs = np.ascontiguousarray(devices, np.int32)
+        self._h = self._l.vsm_dbq_create(_ptr(devs), len(devs), int(nslices or len(devs)))
+        if not self._h:
+            raise VsmError(-2, self._l.vsm_dbq_last_error(None).decode())
+
+    def _check(self, rc):
+        if rc < 0:
+            raise VsmError(rc, self._l.vsm_dbq_last_error(self._h).decode())
+        return rc
+
+    def load(self, rows, layout=LAYOUT_ROWS):
+        rows = np.ascontiguousarray(rows, np.float32)
+        n, dim = rows.shape if layout == LAYOUT_ROWS else rows.shape[::-1]
+        self._check(self._l.vsm_dbq_load(self._h, _ptr(rows), n, dim, layout))
+
+    def slices(self):
+        n = self._l.vsm_dbq_slices(self._h, None)
+        base = np.empty(n + 1, np.int64)
+        self._l.vsm_dbq_slices(self._h, _ptr(base))
+        return base
+
+    def query(self, queries, metric=METRIC_L2, layout=LAYOUT_ROWS):
+        """Returns (k1, k2, i1, i2): keys and global rows of the nearest database row and the runner-up."""
+        queries = np.ascontiguousarray(queries, np.float32)
+        nq = queries.shape[0] if layout == LAYOUT_ROWS else queries.shape[1]
+        k1, k2 = np.empty(nq, np.float32), np.empty(nq, np.float32)
+        i1, i2 = np.empty(nq, np.int64), np.empty(nq, np.int64)
+        self._check(self._l.vsm_dbq_query(self._h, _ptr(queries), nq, layout, metric, _ptr(k1), _ptr(k2), _ptr(i1), _ptr(i2)))
+        return k1, k2, i1, i2
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.vsm_dbq_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

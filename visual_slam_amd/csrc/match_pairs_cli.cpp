@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -23,7 +24,8 @@ namespace {
 
 struct Options {
     std::string sift_dir, out = "matching.txt", name_ext = ".jpg", sift_ext = ".sift";
-    int num = 0, device = 0, batch = 4096;
+    int num = 0, batch = 4096;
+    std::vector<int> devices{0};   // one matching context, with its own copy of every descriptor set, per entry
     int shard = 0, nshards = 1;
     bool exhaustive = true, mutual = true, write_mat = false, append = false;
     bool by_vocab = false;        // pair list from a visual vocabulary (vsm_shortlist_pairs)
@@ -72,6 +74,10 @@ void usage()
             "                        verified pair (E = K^T F K decomposed); with --mat it goes into the records (NE, R, T)\n"
             "  --name-ext EXT        image-name suffix in the match txt (default .jpg)\n"
             "  --device N, --batch P (pairs per GPU submission, default 4096; two are in flight)\n"
+            "  --devices A,B,...     several GPUs of this machine in one process: every one holds all descriptors and takes\n"
+            "                        the next submission of the pair list when it is free; one writer thread emits the\n"
+            "                        results in pair order, so FILE (and the .mat records, the verification outputs) are\n"
+            "                        byte for byte those of a one-GPU run.  A device may be named twice (two contexts)\n"
             "  --shard R/W           match only the R-th of W contiguous slices of the pair list, cut at equal\n"
             "                        shares of the work (rows x rows per pair) (one process\n"
             "                        per GPU); with W > 1 the text goes to FILE.partR: concatenating the parts in\n"
@@ -136,7 +142,20 @@ bool parse(int argc, char** argv, Options& o)
             o.have_camera = true;
         }
         else if (a == "--name-ext") { if (!(v = next("--name-ext"))) return false; o.name_ext = v; }
-        else if (a == "--device") { if (!(v = next("--device"))) return false; o.device = atoi(v); }
+        else if (a == "--device") { if (!(v = next("--device"))) return false; o.devices.assign(1, atoi(v)); }
+        else if (a == "--devices") {
+            if (!(v = next("--devices"))) return false;
+            o.devices.clear();
+            for (const char* p = v; *p;) {
+                char* end = nullptr;
+                const long d = strtol(p, &end, 10);
+                if (end == p || d < 0) { fprintf(stderr, "--devices wants a list of device numbers, e.g. 0,1,2,3\n"); return false; }
+                o.devices.push_back((int)d);
+                p = *end == ',' ? end + 1 : end;
+                if (*end && *end != ',') { fprintf(stderr, "--devices wants a list of device numbers, e.g. 0,1,2,3\n"); return false; }
+            }
+            if (o.devices.empty()) { fprintf(stderr, "--devices wants at least one device\n"); return false; }
+        }
         else if (a == "--batch") { if (!(v = next("--batch"))) return false; o.batch = atoi(v); }
         else if (a == "--shard") {
             if (!(v = next("--shard"))) return false;
@@ -166,6 +185,29 @@ bool parse(int argc, char** argv, Options& o)
 
 }  // namespace
 
+// One matching context: a GPU (or a second context on one), its copy of every image's descriptors and keypoints.
+struct Device {
+    int dev = 0;
+    vsm_ctx* ctx = nullptr;
+    std::vector<int> set_id, xy_id;
+};
+
+// The results of one submission on their way from the GPU side to the writer.
+struct Batch {
+    long long index = -1, lo = 0;
+    int take = 0;
+    bool ready = false;   // filled and waiting for the writer (guarded by the driver's mutex)
+    std::vector<int32_t> idx0, idx1;
+    std::vector<int64_t> off;
+    // geometric verification
+    std::vector<float> F;
+    std::vector<int32_t> nf, in0, in1;
+    std::vector<int64_t> in_off;
+    // relative pose (--camera)
+    std::vector<float> R, T, cams;
+    std::vector<int32_t> ne;
+};
+
 int main(int argc, char** argv)
 {
     Options o;
@@ -173,16 +215,24 @@ int main(int argc, char** argv)
         usage();
         return 2;
     }
-    vsm_ctx* ctx = vsm_create(o.device);
-    if (!ctx) {
-        fprintf(stderr, "vsm_create: %s\n", vsm_last_error(nullptr));
-        return 1;
+    const int ndev = (int)o.devices.size();
+    std::vector<Device> devs(ndev);
+    for (int d = 0; d < ndev; ++d) {
+        devs[d].dev = o.devices[d];
+        devs[d].ctx = vsm_create(o.devices[d]);
+        if (!devs[d].ctx) {
+            fprintf(stderr, "vsm_create(%d): %s\n", o.devices[d], vsm_last_error(nullptr));
+            return 1;
+        }
+        devs[d].set_id.assign(o.num, -1);
+        devs[d].xy_id.assign(o.num, -1);
     }
+    vsm_ctx* ctx = devs[0].ctx;   // pair lists by content are made on the first context
     const auto t_start = std::chrono::steady_clock::now();
 
     // ---- load and upload every image's descriptors once: files are read by a few threads, 256 at a
-    // time, and uploaded in order by this one
-    std::vector<int> set_id(o.num, -1), count(o.num, 0), xy_id(o.num, -1);
+    // time, and uploaded in order, every context by a thread of its own
+    std::vector<int> count(o.num, 0);
     const bool verify = o.verify > 0.0f;
     // words drawn from the images: vocab_size / num rows of each (one more from the first vocab_size % num), evenly spread
     const bool draw_words = o.by_vocab && o.vocab_file.empty() && o.kmeans <= 0;
@@ -191,7 +241,7 @@ int main(int argc, char** argv)
         const int kChunk = 256;
         const int nthreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
         std::vector<std::vector<uint8_t>> des(kChunk);
-        std::vector<std::vector<float>> loc(kChunk);
+        std::vector<std::vector<float>> loc(kChunk), xy(kChunk);
         std::vector<int> np(kChunk), bad(kChunk), nlocs(kChunk);
         for (int base = 0; base < o.num; base += kChunk) {
             const int m = std::min(kChunk, o.num - base);
@@ -208,6 +258,14 @@ int main(int argc, char** argv)
                         if (verify && n > 0 && nloc < 2) bad[k] = 1;
                         np[k] = n;
                         nlocs[k] = nloc;
+                        if (verify && !bad[k]) {
+                            // x, y are the first two columns of a location record
+                            xy[k].resize((size_t)n * 2 + 1);
+                            for (int r = 0; r < n; ++r) {
+                                xy[k][2 * r] = loc[k][(size_t)r * nloc];
+                                xy[k][2 * r + 1] = loc[k][(size_t)r * nloc + 1];
+                            }
+                        }
                     }
                 });
             for (auto& r : readers) r.join();
@@ -225,27 +283,37 @@ int main(int argc, char** argv)
                         words.insert(words.end(), row, row + VSM_DESC_DIM_U8);
                     }
                 }
-                set_id[i] = vsm_upload_u8(ctx, des[k].data(), np[k]);
-                if (set_id[i] < 0) {
-                    fprintf(stderr, "upload %d%s: %s\n", i, o.sift_ext.c_str(), vsm_last_error(ctx));
+            }
+            std::vector<std::string> up_err(ndev);
+            auto upload = [&](int d) {
+                for (int k = 0; k < m; ++k) {
+                    const int i = base + k;
+                    devs[d].set_id[i] = vsm_upload_u8(devs[d].ctx, des[k].data(), np[k]);
+                    if (devs[d].set_id[i] < 0) {
+                        up_err[d] = "upload " + std::to_string(i) + o.sift_ext + ": " + vsm_last_error(devs[d].ctx);
+                        return;
+                    }
+                    if (verify) {
+                        devs[d].xy_id[i] = vsm_upload_xy(devs[d].ctx, xy[k].data(), np[k]);
+                        if (devs[d].xy_id[i] < 0) {
+                            up_err[d] = "upload keypoints " + std::to_string(i) + ": " + vsm_last_error(devs[d].ctx);
+                            return;
+                        }
+                    }
+                }
+            };
+            std::vector<std::thread> uploaders;
+            for (int d = 1; d < ndev; ++d) uploaders.emplace_back(upload, d);
+            upload(0);
+            for (auto& u : uploaders) u.join();
+            for (int d = 0; d < ndev; ++d)
+                if (!up_err[d].empty()) {
+                    fprintf(stderr, "%s\n", up_err[d].c_str());
                     return 1;
                 }
-                if (verify) {
-                    // x, y are the first two columns of a location record
-                    std::vector<float> xy((size_t)np[k] * 2 + 1);
-                    for (int r = 0; r < np[k]; ++r) {
-                        xy[2 * r] = loc[k][(size_t)r * nlocs[k]];
-                        xy[2 * r + 1] = loc[k][(size_t)r * nlocs[k] + 1];
-                    }
-                    xy_id[i] = vsm_upload_xy(ctx, xy.data(), np[k]);
-                    if (xy_id[i] < 0) {
-                        fprintf(stderr, "upload keypoints %d: %s\n", i, vsm_last_error(ctx));
-                        return 1;
-                    }
-                }
-            }
         }
     }
+    const std::vector<int>& set_id = devs[0].set_id;
 
     const double load_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 
@@ -380,190 +448,193 @@ int main(int argc, char** argv)
     prm.min_score = -1e30f;
     prm.max_dist_sq_f = -1.0f;
 
-    // The GPU side (this thread) and the writers (text formatting, .mat records) overlap: results of
-    // submission k are written by the worker while submission k + 1 runs.  Two result buffers.
-    struct Batch {
-        long long lo = 0;
-        int take = 0;
-        std::vector<int32_t> idx0, idx1;
-        std::vector<int64_t> off;
-        // geometric verification
-        std::vector<float> F;
-        std::vector<int32_t> nf, in0, in1;
-        std::vector<int64_t> in_off;
-        // relative pose (--camera)
-        std::vector<float> R, T, cams;
-        std::vector<int32_t> ne;
-    } batches[2];
+    // The GPU side (a thread per context) and the writer (text formatting, .mat records) overlap.  Submissions are
+    // handed out in pair-list order to whichever context is free; every context keeps two of them in flight (the
+    // next one is queued before the lists of the last one are collected) and has two result buffers; the one writer
+    // thread takes the finished submissions in pair-list order, so the files do not depend on which GPU matched what.
     std::mutex mu;
     std::condition_variable cv;
-    int filled[2] = {0, 0};   // 0 = free for the GPU side, 1 = waiting for the writer
-    bool finished = false;
-    // set by the writer thread, read by the GPU thread: the message is published before the flag
-    // (release / acquire), and only the writer thread reads the flag relaxed
-    std::atomic<bool> write_failed{false};
-    std::string write_error;
+    std::map<long long, Batch*> ready;
+    std::vector<Batch> batches((size_t)ndev * 2);
+    // set by whoever fails, read by everyone: the message is published before the flag (release / acquire)
+    std::atomic<bool> failed{false};
+    std::string fail_msg;
+    auto fail = [&](const std::string& msg) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!failed.load(std::memory_order_relaxed)) fail_msg = msg;
+            failed.store(true, std::memory_order_release);
+        }
+        cv.notify_all();
+    };
+    const long long nbatches = (npairs + o.batch - 1) / o.batch;
 
     vsm_matwriter* mw = o.write_mat ? vsm_mat_writer_open(o.num, 0) : nullptr;
     std::thread writer([&]() {
-        for (int cur = 0;; cur ^= 1) {
+        for (long long next = 0; next < nbatches; ++next) {
+            Batch* bp = nullptr;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return filled[cur] == 1 || finished; });
-                if (filled[cur] != 1) return;
+                cv.wait(lk, [&] { return ready.count(next) != 0 || failed.load(std::memory_order_acquire); });
+                if (failed.load(std::memory_order_acquire)) return;
+                bp = ready[next];
+                ready.erase(next);
             }
-            Batch& b = batches[cur];
-            for (int k = 0; k < b.take && !write_failed; ++k) {
+            Batch& b = *bp;
+            for (int k = 0; k < b.take && !failed.load(std::memory_order_acquire); ++k) {
                 const int ia = pairs[2 * (b.lo + k)], ib = pairs[2 * (b.lo + k) + 1];
                 const int nm = (int)(b.off[k + 1] - b.off[k]);
                 const std::string n0 = std::to_string(ia) + o.name_ext, n1 = std::to_string(ib) + o.name_ext;
                 if (vsm_matchtxt_write(tw, n0.c_str(), n1.c_str(), b.idx0.data() + b.off[k], b.idx1.data() + b.off[k], nm,
                                        count[ia]) < 0) {
-                    write_error = "write error on " + o.out;
-                    write_failed.store(true, std::memory_order_release);
+                    fail("write error on " + o.out);
+                    break;
                 }
-                if (o.write_mat && !write_failed) {
+                if (o.write_mat) {
                     const std::string p0 = o.sift_dir + "/" + std::to_string(ia), p1 = o.sift_dir + "/" + std::to_string(ib);
                     const int rc = vsm_mat_writer_put(mw, p0.c_str(), p1.c_str(), count[ia], count[ib], nm,
                                                       b.idx0.data() + b.off[k], b.idx1.data() + b.off[k]);
                     if (rc < 0) {
-                        write_error = "cannot write .mat for pair " + std::to_string(ia) + " " + std::to_string(ib);
-                        write_failed.store(true, std::memory_order_release);
+                        fail("cannot write .mat for pair " + std::to_string(ia) + " " + std::to_string(ib));
+                        break;
                     }
                 }
-                if (verify && !write_failed) {
+                if (verify) {
                     const int nin = (int)(b.in_off[k + 1] - b.in_off[k]);
                     const int32_t* q0 = b.in0.data() + b.in_off[k];
                     const int32_t* q1 = b.in1.data() + b.in_off[k];
                     if (tw_in && vsm_matchtxt_write(tw_in, n0.c_str(), n1.c_str(), q0, q1, nin, count[ia]) < 0) {
-                        write_error = "write error on " + o.inlier_out;
-                        write_failed.store(true, std::memory_order_release);
+                        fail("write error on " + o.inlier_out);
+                        break;
                     }
-                    if (o.write_mat && !write_failed) {
+                    if (o.write_mat) {
                         const std::string p0 = o.sift_dir + "/" + std::to_string(ia), p1 = o.sift_dir + "/" + std::to_string(ib);
                         const int rc = o.have_camera
                             ? vsm_mat_writer_put_ematch(mw, p0.c_str(), p1.c_str(), nin, q0, q1, b.F.data() + (size_t)k * 9, b.ne[k],
                                                         b.R.data() + (size_t)k * 9, b.T.data() + (size_t)k * 3, o.camera[0], o.camera[0])
                             : vsm_mat_writer_put_fmatch(mw, p0.c_str(), p1.c_str(), nin, q0, q1, b.F.data() + (size_t)k * 9);
                         if (rc < 0) {
-                            write_error = "cannot write inlier record for pair " + std::to_string(ia) + " " + std::to_string(ib);
-                            write_failed.store(true, std::memory_order_release);
+                            fail("cannot write inlier record for pair " + std::to_string(ia) + " " + std::to_string(ib));
+                            break;
                         }
                     }
                 }
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
-                filled[cur] = 0;
+                b.ready = false;
             }
             cv.notify_all();
         }
     });
 
-    // GPU side: submission k + 1 is queued before the lists of submission k are collected, so the
-    // device never waits for this thread or for the writer
-    std::vector<int32_t> ids, xy_ids;
-    long long total = 0, total_inliers = 0, pairs_with_geometry = 0, pairs_with_pose = 0;
-    bool gpu_failed = false;
-    const long long nbatches = (npairs + o.batch - 1) / o.batch;
-    auto submit = [&](long long k) {
-        const long long lo = k * o.batch;
-        const int take = (int)std::min<long long>(o.batch, npairs - lo);
-        ids.resize((size_t)take * 2);
-        for (int q = 0; q < take; ++q) {
-            ids[2 * q] = set_id[pairs[2 * (lo + q)]];
-            ids[2 * q + 1] = set_id[pairs[2 * (lo + q) + 1]];
-        }
-        if (vsm_submit_pairs(ctx, ids.data(), take, &prm, VSM_METRIC_L2) != VSM_OK) {
-            fprintf(stderr, "vsm_submit_pairs: %s\n", vsm_last_error(ctx));
-            return false;
-        }
-        return true;
-    };
-    if (nbatches > 0 && !submit(0)) gpu_failed = true;
-    for (long long k = 0; k < nbatches && !gpu_failed; ++k) {
-        if (k + 1 < nbatches && !submit(k + 1)) {
-            gpu_failed = true;
-            break;
-        }
-        const int cur = (int)(k & 1);
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return filled[cur] == 0; });
-        }
-        if (write_failed.load(std::memory_order_acquire)) break;
-        Batch& b = batches[cur];
-        const long long lo = k * o.batch;
-        const int take = (int)std::min<long long>(o.batch, npairs - lo);
-        size_t cap = 1;
-        for (int q = 0; q < take; ++q) cap += (size_t)count[pairs[2 * (lo + q)]];
-        b.lo = lo;
-        b.take = take;
-        b.idx0.resize(cap);
-        b.idx1.resize(cap);
-        b.off.resize((size_t)take + 1);
-        const long long got = vsm_collect_matches(ctx, b.off.data(), b.idx0.data(), b.idx1.data(), (long long)cap);
-        if (got < 0) {
-            fprintf(stderr, "vsm_collect_matches: %s\n", vsm_last_error(ctx));
-            gpu_failed = true;
-            break;
-        }
-        total += got;
-        if (verify) {
-            // the lists just collected are still on the device: verify them there
-            xy_ids.resize((size_t)take * 2);
+    std::atomic<long long> next_batch{0};
+    std::atomic<long long> total{0}, total_inliers{0}, pairs_with_geometry{0}, pairs_with_pose{0};
+    auto gpu_side = [&](int d) {
+        Device& D = devs[d];
+        std::vector<int32_t> ids, xy_ids;
+        auto grab = [&]() -> long long {
+            if (failed.load(std::memory_order_acquire)) return -1;
+            const long long k = next_batch.fetch_add(1);
+            return k < nbatches ? k : -1;
+        };
+        auto submit = [&](long long k) {
+            const long long lo = k * o.batch;
+            const int take = (int)std::min<long long>(o.batch, npairs - lo);
+            ids.resize((size_t)take * 2);
             for (int q = 0; q < take; ++q) {
-                xy_ids[2 * q] = xy_id[pairs[2 * (lo + q)]];
-                xy_ids[2 * q + 1] = xy_id[pairs[2 * (lo + q) + 1]];
+                ids[2 * q] = D.set_id[pairs[2 * (lo + q)]];
+                ids[2 * q + 1] = D.set_id[pairs[2 * (lo + q) + 1]];
             }
-            b.F.resize((size_t)take * 9);
-            b.nf.resize((size_t)take);
-            b.in_off.resize((size_t)take + 1);
-            b.in0.resize((size_t)got + 1);
-            b.in1.resize((size_t)got + 1);
-            gprm.first_pair = first_of_shard + lo;   // global position in the pair list: sharding and batching do not change the samples
-            const long long gin = vsm_verify_matches(ctx, xy_ids.data(), take, nullptr, nullptr, nullptr, &gprm, b.F.data(),
-                                                     b.nf.data(), b.in_off.data(), b.in0.data(), b.in1.data(), got);
-            if (gin < 0) {
-                fprintf(stderr, "vsm_verify_matches: %s\n", vsm_last_error(ctx));
-                gpu_failed = true;
-                break;
+            if (vsm_submit_pairs(D.ctx, ids.data(), take, &prm, VSM_METRIC_L2) != VSM_OK) {
+                fail(std::string("vsm_submit_pairs: ") + vsm_last_error(D.ctx));
+                return false;
             }
-            total_inliers += gin;
-            for (int q = 0; q < take; ++q) pairs_with_geometry += b.nf[q] > 0;
-            if (o.have_camera) {
-                b.R.resize((size_t)take * 9);
-                b.T.resize((size_t)take * 3);
-                b.ne.resize((size_t)take);
-                b.cams.resize((size_t)take * 8);
-                for (int q = 0; q < take; ++q)
-                    for (int e = 0; e < 8; ++e) b.cams[(size_t)q * 8 + e] = o.camera[e & 3];
-                const int np = vsm_recover_pose(ctx, xy_ids.data(), take, b.cams.data(), b.F.data(), b.in_off.data(), b.in0.data(),
-                                                b.in1.data(), b.R.data(), b.T.data(), b.ne.data());
-                if (np < 0) {
-                    fprintf(stderr, "vsm_recover_pose: %s\n", vsm_last_error(ctx));
-                    gpu_failed = true;
-                    break;
+            return true;
+        };
+        vsm_geom_params g = gprm;
+        long long cur = grab();
+        if (cur < 0 || !submit(cur)) return;
+        for (int slot = 0; cur >= 0; slot ^= 1) {
+            const long long nxt = grab();
+            if (nxt >= 0 && !submit(nxt)) return;
+            Batch& b = batches[(size_t)d * 2 + slot];
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !b.ready || failed.load(std::memory_order_acquire); });
+            }
+            if (failed.load(std::memory_order_acquire)) return;
+            const long long lo = cur * o.batch;
+            const int take = (int)std::min<long long>(o.batch, npairs - lo);
+            size_t cap = 1;
+            for (int q = 0; q < take; ++q) cap += (size_t)count[pairs[2 * (lo + q)]];
+            b.index = cur;
+            b.lo = lo;
+            b.take = take;
+            b.idx0.resize(cap);
+            b.idx1.resize(cap);
+            b.off.resize((size_t)take + 1);
+            const long long got = vsm_collect_matches(D.ctx, b.off.data(), b.idx0.data(), b.idx1.data(), (long long)cap);
+            if (got < 0) {
+                fail(std::string("vsm_collect_matches: ") + vsm_last_error(D.ctx));
+                return;
+            }
+            total += got;
+            if (verify) {
+                // the lists just collected are still on the device: verify them there
+                xy_ids.resize((size_t)take * 2);
+                for (int q = 0; q < take; ++q) {
+                    xy_ids[2 * q] = D.xy_id[pairs[2 * (lo + q)]];
+                    xy_ids[2 * q + 1] = D.xy_id[pairs[2 * (lo + q) + 1]];
                 }
-                pairs_with_pose += np;
+                b.F.resize((size_t)take * 9);
+                b.nf.resize((size_t)take);
+                b.in_off.resize((size_t)take + 1);
+                b.in0.resize((size_t)got + 1);
+                b.in1.resize((size_t)got + 1);
+                g.first_pair = first_of_shard + lo;   // global position in the pair list: sharding and batching do not change the samples
+                const long long gin = vsm_verify_matches(D.ctx, xy_ids.data(), take, nullptr, nullptr, nullptr, &g, b.F.data(),
+                                                         b.nf.data(), b.in_off.data(), b.in0.data(), b.in1.data(), got);
+                if (gin < 0) {
+                    fail(std::string("vsm_verify_matches: ") + vsm_last_error(D.ctx));
+                    return;
+                }
+                total_inliers += gin;
+                long long with = 0;
+                for (int q = 0; q < take; ++q) with += b.nf[q] > 0;
+                pairs_with_geometry += with;
+                if (o.have_camera) {
+                    b.R.resize((size_t)take * 9);
+                    b.T.resize((size_t)take * 3);
+                    b.ne.resize((size_t)take);
+                    b.cams.resize((size_t)take * 8);
+                    for (int q = 0; q < take; ++q)
+                        for (int e = 0; e < 8; ++e) b.cams[(size_t)q * 8 + e] = o.camera[e & 3];
+                    const int np = vsm_recover_pose(D.ctx, xy_ids.data(), take, b.cams.data(), b.F.data(), b.in_off.data(), b.in0.data(),
+                                                    b.in1.data(), b.R.data(), b.T.data(), b.ne.data());
+                    if (np < 0) {
+                        fail(std::string("vsm_recover_pose: ") + vsm_last_error(D.ctx));
+                        return;
+                    }
+                    pairs_with_pose += np;
+                }
             }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                b.ready = true;
+                ready[cur] = &b;
+            }
+            cv.notify_all();
+            cur = nxt;
         }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            filled[cur] = 1;
-        }
-        cv.notify_all();
-    }
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return filled[0] == 0 && filled[1] == 0; });
-        finished = true;
-    }
-    cv.notify_all();
+    };
+    std::vector<std::thread> gpu_threads;
+    for (int d = 1; d < ndev; ++d) gpu_threads.emplace_back(gpu_side, d);
+    gpu_side(0);
+    for (auto& t : gpu_threads) t.join();
     writer.join();
-    if (gpu_failed) return 1;
-    if (write_failed.load(std::memory_order_acquire)) {
-        fprintf(stderr, "%s\n", write_error.c_str());
+    if (failed.load(std::memory_order_acquire)) {
+        fprintf(stderr, "%s\n", fail_msg.c_str());
         return 1;
     }
     if (mw && vsm_mat_writer_close(mw) != VSM_OK) {
@@ -580,11 +651,11 @@ int main(int argc, char** argv)
     }
     if (verify)
         fprintf(stderr, "geometric verification: %lld pairs with a fundamental matrix, %lld inlier matches\n",
-                pairs_with_geometry, total_inliers);
-    if (o.have_camera) fprintf(stderr, "relative pose: %lld pairs\n", pairs_with_pose);
+                pairs_with_geometry.load(), total_inliers.load());
+    if (o.have_camera) fprintf(stderr, "relative pose: %lld pairs\n", pairs_with_pose.load());
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-    fprintf(stderr, "%d images, %lld pairs, %lld matches, %.3f s (%.0f pairs/s); reading + upload %.3f s, matching + writing %.3f s\n",
-            o.num, npairs, total, secs, npairs / secs, load_secs, secs - load_secs);
-    vsm_destroy(ctx);
+    fprintf(stderr, "%d images, %lld pairs, %lld matches, %.3f s (%.0f pairs/s) on %d context%s; reading + upload %.3f s, matching + writing %.3f s\n",
+            o.num, npairs, total.load(), secs, npairs / secs, ndev, ndev == 1 ? "" : "s", load_secs, secs - load_secs);
+    for (Device& D : devs) vsm_destroy(D.ctx);
     return 0;
 }
