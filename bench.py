@@ -43,27 +43,37 @@ def measured_traffic(kernel, summary="r02_traffic_sift_exhaustive.json"):
         return None
 
 
-def measured_mfma_busy(kernel):
-    """Fraction of the elapsed SIMD cycles in which the matrix pipes were busy, from the committed counter
-    pass (profiles/r02_mfma_utilisation.txt, written by tools/refresh_profiles.sh); None when absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_mfma_utilisation.txt")
+def measured_mfma_busy(kernel, summary="r02_mfma_utilisation.txt"):
+    """Fraction of the elapsed SIMD cycles in which the matrix pipes were busy, from a committed counter
+    pass (profiles/<summary>, written by tools/refresh_profiles.sh or tools/bf16_counters.sh: the kernel's name at the
+    start of a line, the fraction after "SIMDs) = " on that line or the next); None when absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", summary)
     try:
-        for line in open(path):
-            if line.startswith(kernel + ":") and "SIMDs) = " in line:
-                return float(line.split("SIMDs) = ")[1].split(";")[0])
+        lines = open(path).read().splitlines()
+        for k, line in enumerate(lines):
+            if line.startswith(kernel + ":") or line.startswith(kernel + " launches"):
+                for cand in lines[k:k + 2]:
+                    if "SIMDs) = " in cand:
+                        return float(cand.split("SIMDs) = ")[1].split(";")[0])
     except (OSError, ValueError, IndexError):
         pass
     return None
 
 
-def f32_roofline(m, flops, kms):
+def f32_roofline(m, flops, kms, busy_of=None):
     """Roofline object of a float-descriptor search: priced against the matrix-core peak of the
-    path that actually ran (bf16 coarse pass + exact re-rank, or the f32-input kernel)."""
+    path that actually ran (bf16 coarse pass + exact re-rank, or the f32-input kernel).  busy_of = (kernel name,
+    summary file under profiles/) of the committed counter pass over this workload's shape, if there is one."""
     fast = m.last_f32_path() == 0
     peak = BF16_DENSE_PEAK_TFLOPS if fast else F32_MFMA_PEAK_TFLOPS
     achieved = flops / (kms * 1e-3) / 1e12
+    busy = measured_mfma_busy(*busy_of) if (fast and busy_of) else None
     return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": None, "kernel": "bf16_coarse_kernel" if fast else "f32_knn_kernel", "kernel_ms": kms,
+            "mfma_busy_frac": busy,
+            "mfma_busy_note": ("matrix-pipe busy cycles / (elapsed cycles x SIMDs) of the coarse kernel: a constant read from a "
+                               "committed counter pass over the same shape (profiles/%s), not a measurement of this run"
+                               % busy_of[1]) if busy is not None else None,
             "note": ("bf16 MFMA coarse pass + exact f32 re-rank of the survivors (bit-identical results); "
                      "kernel_ms brackets coarse + re-rank of every direction searched") if fast else
                     "f32-input MFMA path; kernel_ms includes the merge kernels"}
@@ -524,7 +534,8 @@ def run_superpoint_pairs(args, torch, dist, world, rank):
         "config": {"workload": "exhaustive SuperPoint-256 f32 matching, %d images x %d keypoints, mutual-NN, "
                                "%d pairs per step per GPU, match lists copied to host" % (nimg, n, pps),
                    "parallelism": "pair list sharded x%d" % world, "matches_per_pair": nmatch / max(npairs, 1)},
-        "roofline": f32_roofline(m, OPS_PER_EVAL_F32 * float(pps) * n * n, kms),
+        "roofline": f32_roofline(m, OPS_PER_EVAL_F32 * float(pps) * n * n, kms,
+                                 ("void vsm::bf16_coarse_kernel<256, true, false>", "r03_f32pairs_mfma_utilisation.txt")),
     }
     m.close()
     return out
@@ -626,7 +637,7 @@ def run_geom_verify(args, torch, dist, world, rank):
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
         import oracle_lib as orc
         ok = True
-        for p in range(0, npairs, npairs // 16):
+        for p in range(0, npairs, max(1, npairs // 16)):
             sc = scenes[p % nscene]
             oF, o0, o1 = orc.geom_pair(sc[4], sc[5], sc[2], sc[3], max_sampson=2.0, hypotheses=hyp, seed=7, pair_pos=p)
             lo, hi = int(in_off[p]), int(in_off[p + 1])
@@ -653,6 +664,8 @@ def run_geom_verify(args, torch, dist, world, rank):
     if world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
         import oracle_lib as orc
+        threads, avail = host_threads()
+        orc.lib().oracle_geom_set_threads(threads)    # the oracle's loop over samples: the threads the SIFT baseline uses
         t1 = time.perf_counter()
         done = 0
         while time.perf_counter() - t1 < args.cpu_seconds:
@@ -660,7 +673,7 @@ def run_geom_verify(args, torch, dist, world, rank):
             orc.geom_pair(sc[4], sc[5], sc[2], sc[3], max_sampson=2.0, hypotheses=hyp, seed=7, pair_pos=done)
             done += 1
         el = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": done / el, "unit": "pairs/s", "cores": orc.THREADS, "kind": "port",
+        out["cpu_baseline"] = {"value": done / el, "unit": "pairs/s", "cores": threads, "host_cpus": avail, "kind": "port",
                                "sample": "oracle RANSAC on %d pairs of the same shape, %.1f s" % (done, el)}
     m.close()
     return out
@@ -800,8 +813,11 @@ def run_db_query(args, torch, dist, world, rank):
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "verified": verified,
         "config": {"workload": "16384 float-256 queries vs 1M-row database, k=2, L2",
-                   "parallelism": "database sliced x%d, RCCL all-gather of the per-slice 2-NN lists, device merge" % world},
-        "roofline": f32_roofline(m, OPS_PER_EVAL_F32 * float(nq) * (hi - lo), kms),
+                   "parallelism": "database sliced x%d, %s of the per-slice 2-NN lists, device merge"
+                                  % (world, "all-gather over gloo on host copies (rehearsal on one GPU)" if REHEARSAL else "RCCL all-gather")},
+        "roofline": f32_roofline(m, OPS_PER_EVAL_F32 * float(nq) * (hi - lo), kms,
+                                 ("void vsm::bf16_coarse_kernel<256, false, false>", "r03_dbquery_mfma_utilisation.txt")
+                                 if world == 1 else None),
     }
     if world == 1 and m.last_f32_path() == 0:   # the counter passes were taken at this shape
         out["roofline"]["traffic"] = measured_traffic("void vsm::bf16_coarse_kernel<256, false, false>", "r02_traffic_db_query.json")
@@ -853,10 +869,17 @@ def main():
           "sift_large_pair": run_sift_large_pair, "db_query": run_db_query, "geom_verify": run_geom_verify,
           "shortlist": run_shortlist}[args.workload]
     out = fn(args, torch, dist, world, rank)
+    failed = out.get("verified") is False     # (the same on every rank: the flag is summed over the ranks)
+    if failed:
+        # a result that differs from the oracle's is not a measurement: no value, no roofline, a failing exit status
+        out = {k: v for k, v in out.items() if k not in ("value", "roofline", "pairs_per_s", "queries_per_s")}
+        out["error"] = "the timed run's output differs from the CPU oracle's"
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -190,6 +190,8 @@ long long vsm_fetch_matches(vsm_ctx* ctx, int64_t* offsets, int32_t* idx0, int32
  * squared distances: the two best rows are found by the key |b|^2 - 2 a.b the matrix cores
  * compute, then ordered, and their distances reported, in difference form sum (a[k] - b[k])^2
  * (what the reference ranks by, model_2_0.py:68; exact to 1e-5 relative for near-duplicates too).
+ * Three or more rows within the key's rounding error (about 1e-7 of |a|^2 + |b|^2) of one another are beyond what
+ * this settles: only the key's two best rows are compared in difference form.
  * idx2 may be NULL.  Brute-force 1-NN of
  * NearestEmbedFunc.forward (model_2_0.py:43-78) is the k=1 part of this call. */
 int vsm_knn2(vsm_ctx* ctx, int set_q, int set_db, int metric,
@@ -291,8 +293,11 @@ float vsm_last_verify_ms(vsm_ctx* ctx);
 
 /* ---- VisualSfM interchange files (host only, no device needed) ------------------- */
 /* FeatureData::ReadSIFTB(file, locbuf, desbuf, nmax) (FeaturePoints.cpp:516-531) with
- * the header checks of the member reader (:388-446).  NULL buffers query the header.
- * Returns the number of features stored in the file (0 on failure). */
+ * the header checks of the member reader (:388-446).  With a buffer it returns what that call returns: the rows
+ * now in the buffers, min(nmax, rows in the file) (0 on failure, and for nmax <= 0); locbuf receives that many
+ * location rows (the reference call copies the locations of ALL rows of the file into locbuf whatever nmax is).
+ * With both buffers NULL it only reads the header and returns the rows in the file; *npoint and *nloc_dim (each
+ * may be NULL) receive the header's values either way. */
 int vsm_sift_read(const char* path, float* locbuf, uint8_t* desbuf, int nmax,
                   int* npoint, int* nloc_dim);
 /* FeatureData::saveSIFTB2 (FeaturePoints.cpp:228-280).  Returns 1/0. */

@@ -17,6 +17,7 @@
  *   binary tree, unpivoted LU of the normal matrix, five inverse iterations from (1, ..., 1)); the matrix
  *   with most inliers among the five (earliest of equals), its inliers listed in match order. */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -500,3 +501,6 @@ int oracle_pose_pair(const float* xy0, int n0, const float* xy1, int n1, const i
     return cnt[best];
 }
 
+
+/* Threads of the loop over samples in oracle_geom_pair (the other oracles take the count as an argument). */
+void oracle_geom_set_threads(int threads) { omp_set_num_threads(threads > 0 ? threads : 1); }

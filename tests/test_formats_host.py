@@ -78,6 +78,31 @@ def test_sift_roundtrip_and_bytes(tmp_path):
         np.testing.assert_array_equal(l3, loc[:max(1, n // 2)])
 
 
+def test_sift_read_returns_what_the_reference_call_returns(tmp_path):
+    """FeatureData::ReadSIFTB(file, locbuf, desbuf, nmax) returns min(nmax, npoint), the rows now in the caller's
+    buffers (FeaturePoints.cpp:524-529): a caller written against it may use the value as exactly that."""
+    import ctypes as C
+    from visual_slam_amd import _binding as B
+    rng = np.random.default_rng(3)
+    loc = rng.random((10, 5)).astype(np.float32)
+    des = rng.integers(0, 256, (10, 128), dtype=np.uint8)
+    p = str(tmp_path / "ten.sift").encode()
+    host.write_sift(p.decode(), loc, des)
+    lib = B.lib()
+    npoint, nloc = C.c_int(0), C.c_int(0)
+    assert lib.vsm_sift_read(p, None, None, 0, C.byref(npoint), C.byref(nloc)) == 10      # header query
+    assert (npoint.value, nloc.value) == (10, 5)
+    for nmax, want in ((4, 4), (10, 10), (25, 10), (0, 0), (-3, 0)):
+        lb = np.full((25, 5), -1.0, np.float32)
+        db = np.full((25, 128), 7, np.uint8)
+        assert lib.vsm_sift_read(p, B._ptr(lb), B._ptr(db), nmax, C.byref(npoint), None) == want
+        assert npoint.value == 10
+        np.testing.assert_array_equal(db[:want], des[:want])
+        np.testing.assert_array_equal(lb[:want], loc[:want])
+        assert (db[want:] == 7).all() and (lb[want:] == -1.0).all()                       # nothing past the rows returned
+    assert lib.vsm_sift_read(p, None, B._ptr(db), 3, None, None) == 3                     # descriptors only
+
+
 def test_sift_reader_rejects_bad_files(tmp_path):
     p = str(tmp_path / "bad.sift")
     loc = np.zeros((2, 5), np.float32)

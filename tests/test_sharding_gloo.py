@@ -36,15 +36,20 @@ def _worker(rank, world, port, tmpdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
     # ---- pair-list sharding: contiguous shards, every pair exactly once -------------------
+    # (the cut every rank of bench.py makes: bench.shard_bounds; 23 images give 253 pairs, an odd count)
+    import bench
     pairs = vsm.generate_exhaustive_pairs(23)
-    per = len(pairs) // world
-    shard = pairs[rank * per:(rank + 1) * per]
-    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([len(shard)], dtype=torch.int64))
-    assert sum(int(c) for c in counts) == per * world
+    lo, hi = bench.shard_bounds(len(pairs), world, rank)
+    shard = pairs[lo:hi]
+    bounds = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(bounds, torch.tensor([lo, hi], dtype=torch.int64))
+    bounds = [b.tolist() for b in bounds]
+    assert bounds[0][0] == 0 and bounds[-1][1] == len(pairs)            # every pair ...
+    assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))   # ... exactly once
+    assert max(b[1] - b[0] for b in bounds) - min(b[1] - b[0] for b in bounds) <= 1
     firsts = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(firsts, torch.tensor(shard[0].tolist(), dtype=torch.int64))
-    assert firsts[rank].tolist() == pairs[rank * per].tolist()
+    assert firsts[rank].tolist() == pairs[lo].tolist()
 
     # ---- sliced database: local 2-NN per rank, all_gather, merge -----------------------------
     rng = np.random.default_rng(42)          # same stream on every rank
@@ -133,4 +138,8 @@ def test_bench_finds_the_committed_counter_figures():
     assert coarse is not None and 5e8 < coarse < 3e9        # the bf16 database is 0.52 GB
     busy = bench.measured_mfma_busy("void vsm::sift_query_tile_kernel<true>")
     assert busy is not None and 0.5 < busy < 1.0
+    for kernel, summary in (("void vsm::bf16_coarse_kernel<256, false, false>", "r03_dbquery_mfma_utilisation.txt"),
+                            ("void vsm::bf16_coarse_kernel<256, true, false>", "r03_f32pairs_mfma_utilisation.txt")):
+        busy = bench.measured_mfma_busy(kernel, summary)
+        assert busy is not None and 0.5 < busy < 1.0, kernel
     assert bench.shard_bounds(10, 3, 0) == (0, 3) and bench.shard_bounds(10, 3, 2) == (6, 10)

@@ -171,3 +171,16 @@ def test_tool_a2b(tmp_path):
     bl, bd = host.read_sift(str(tmp_path / "7.sift"))
     assert np.array_equal(bl, el) and np.array_equal(bd, ed) and not os.path.exists(p)
     assert subprocess.run([tool, "a2b", str(tmp_path / "none.sift")], capture_output=True).returncode == 1
+
+
+def test_ascii_header_with_an_impossible_count_is_malformed(tmp_path):
+    """A header that announces more features than the file has bytes for is rejected before anything is sized by it."""
+    import ctypes as C
+    from visual_slam_amd import _binding as B
+    p = tmp_path / "huge.sift"
+    p.write_text("2000000000 128\n1 2 3 4\n" + " ".join(["7"] * 128) + "\n")
+    n = C.c_int(-1)
+    assert B.lib().vsm_sift_read_ascii(str(p).encode(), None, None, 0, C.byref(n)) == 0 and n.value == 0
+    assert B.lib().vsm_sift_ascii_to_binary(str(p).encode(), None, 0) == -6          # VSM_EFORMAT
+    p.write_text("1 128\n1 2 3 4\n" + " ".join(["7"] * 128) + "\n")              # the same file with an honest count
+    assert B.lib().vsm_sift_read_ascii(str(p).encode(), None, None, 0, C.byref(n)) == 1 and n.value == 1

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <list>
 #include <memory>
+#include <new>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -139,7 +140,7 @@ extern "C" int vsm_sift_read(const char* path, float* locbuf, uint8_t* desbuf, i
         if (!f.seek((off_t)(sizeof h + loc_bytes))) return 0;
         if (!f.read_exact(desbuf, (size_t)take * VSM_DESC_DIM_U8)) return 0;
     }
-    return h.npoint;
+    return take;   // FeaturePoints.cpp:524-529: the rows now in the caller's buffers, min(nmax, npoint)
 }
 
 extern "C" int vsm_sift_write(const char* path, const float* loc, int nloc_dim,
@@ -221,9 +222,13 @@ extern "C" int vsm_sift_read_ascii(const char* path, float* locbuf, uint8_t* des
     if (npoint) *npoint = 0;
     std::string text;
     if (!path || !slurp(path, &text)) return 0;
+    const size_t file_bytes = text.size();
     Tokens tok(std::move(text));
     int n = 0, nd = 0;
     if (!tok.next_int(&n) || !tok.next_int(&nd) || n <= 0 || nd != VSM_DESC_DIM_U8) return 0;
+    // a feature is 4 + 128 values, each at least one character and a separator: a count the file cannot hold is a
+    // malformed header (and would otherwise size the caller's buffers)
+    if ((size_t)n > file_bytes / (2 * (4 + VSM_DESC_DIM_U8))) return 0;
     if (npoint) *npoint = n;
     if (!locbuf && !desbuf) return n;
     const int take = std::min(std::max(nmax, 0), n);
@@ -339,8 +344,14 @@ extern "C" int vsm_sift_ascii_to_binary(const char* path, char* out_path, int ca
     if (!path) return VSM_EINVAL;
     int n = 0;
     if (!vsm_sift_read_ascii(path, nullptr, nullptr, 0, &n)) return VSM_EFORMAT;
-    std::vector<float> loc((size_t)n * 5);
-    std::vector<uint8_t> des((size_t)n * VSM_DESC_DIM_U8);
+    std::vector<float> loc;
+    std::vector<uint8_t> des;
+    try {   // nothing may be thrown through the C boundary
+        loc.resize((size_t)n * 5);
+        des.resize((size_t)n * VSM_DESC_DIM_U8);
+    } catch (const std::bad_alloc&) {
+        return VSM_ENOMEM;
+    }
     if (!vsm_sift_read_ascii(path, loc.data(), des.data(), n, nullptr)) return VSM_EFORMAT;
     vsm_sift_renormalise(loc.data(), 5, des.data(), n);
     std::string name(path);

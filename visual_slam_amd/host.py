@@ -160,8 +160,8 @@ def read_sift(path, nmax=None):
     n = npoint.value if nmax is None else min(nmax, npoint.value)
     loc = np.empty((n, nloc.value), np.float32)
     des = np.empty((n, 128), np.uint8)
-    ok = B.lib().vsm_sift_read(_b(path), B._ptr(loc), B._ptr(des), n, None, None)
-    if not ok:
+    # with buffers the call returns the rows it put there, min(nmax, rows in the file), as the reference's does
+    if n > 0 and B.lib().vsm_sift_read(_b(path), B._ptr(loc), B._ptr(des), n, None, None) != n:
         raise B.VsmError(-6, "short SIFT file %s" % path)
     return loc, des
 
