@@ -945,16 +945,22 @@ static void launch_coarse_d(const CoarseProblem* d_probs, int nprobs, int blocks
     }
 }
 
+unsigned* coarse_shared_thr(void* scratch, const CoarseTotals& t, int* words)
+{
+    *words = t.max_nsplits > 1 ? (int)(t.out_rows - t.out_rows0) : 0;
+    return reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + part_bytes(t.sublists) + list_bytes(t.sublists));
+}
+
 bool launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
                        int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow,
-                       hipStream_t s, bool top1, bool db_lists)
+                       hipStream_t s, bool top1, bool db_lists, bool thr_cleared)
 {
     if (nprobs <= 0 || t.coarse_blocks <= 0) return false;
     CoarsePart* part = static_cast<CoarsePart*>(scratch);
     uint2* lists = reinterpret_cast<uint2*>(static_cast<char*>(scratch) + part_bytes(t.sublists));
     unsigned* shared_thr = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lists) + list_bytes(t.sublists));
     // the words the splits of a search share: 0 = nothing published yet
-    if (shared_thr && t.max_nsplits > 1) (void)hipMemsetAsync(shared_thr, 0, (size_t)(t.out_rows - t.out_rows0) * sizeof(unsigned), s);
+    if (shared_thr && t.max_nsplits > 1 && !thr_cleared) (void)hipMemsetAsync(shared_thr, 0, (size_t)(t.out_rows - t.out_rows0) * sizeof(unsigned), s);
     const int dimp = f32_dimp(dim);
     if (dimp == 64) launch_coarse_d<64>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s, top1, db_lists);
     else if (dimp == 128) launch_coarse_d<128>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s, top1, db_lists);

@@ -123,9 +123,12 @@ size_t coarse_scratch_bytes(const CoarseTotals& t);
 // survivor list was too short and the results are void.
 // Returns true when L2 results are already ordered and reported in difference form (launch_f32_l2_finish is
 // then not needed), false when they are still keys.
+// thr_cleared: the caller has cleared the words the splits of a search share (coarse_shared_thr) itself.
 bool launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
                        int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow,
-                       hipStream_t s, bool top1 = false, bool db_lists = false);
+                       hipStream_t s, bool top1 = false, bool db_lists = false, bool thr_cleared = false);
+// Where those words lie in the scratch of a group of searches, and how many there are (0: no search is split).
+unsigned* coarse_shared_thr(void* scratch, const CoarseTotals& t, int* words);
 
 // L2 searches only (problems of the other metric are skipped): orders each query's two best rows by the
 // difference-form squared distance and stores those distances in k1 / k2.  Problems come from device memory

@@ -2,18 +2,23 @@
 // (Others/SuperPoint_data/models/superglue.py:276-293: argmax both ways, mutual agreement, score
 // threshold, -1 for "no match") plus the optional distance cap and Lowe ratio test of the L2 ranking.
 #include "vsm_internal.h"
+#include "f32_kernels.h"
 
 #include <math.h>
 
 namespace vsm {
 
+// Four consecutive rows per thread and round: one round (and one set of barriers) for a pair of 4096 rows.
+// copy_out (single-pair calls): when the block is done it copies the listed device words end to end into dst, which
+// is pinned host memory, so the caller needs neither a copy command nor another kernel behind this one.
 __global__ __launch_bounds__(1024)
 void f32_accept_kernel(const SiftPair* __restrict__ pairs, const F32PairRef* __restrict__ refs, F32Rule rule,
                        const int32_t* __restrict__ j1, const float* __restrict__ k1, const float* __restrict__ k2,
-                       SiftOutputs out)
+                       SiftOutputs out, WordSegments copy_out, uint32_t* __restrict__ copy_dst)
 {
     __shared__ int wsum[16];
     __shared__ int base_s;
+    constexpr int R = 4;
     const SiftPair pw = pairs[blockIdx.x];
     const F32PairRef rf = refs[blockIdx.x];
     const int tid = threadIdx.x;
@@ -25,38 +30,47 @@ void f32_accept_kernel(const SiftPair* __restrict__ pairs, const F32PairRef* __r
     __syncthreads();
 
     const bool empty = pw.nA == 0 || pw.nB == 0;
-    for (int i0 = 0; i0 < pw.nA && !empty; i0 += 1024) {
-        const int i = i0 + tid;
-        bool ok = false;
-        int j = -1;
-        float best = 0.0f;
-        if (i < pw.nA) {
-            j = j1[rf.fwd_off + i];
-            best = k1[rf.fwd_off + i];
-            ok = j >= 0;
+    for (int i0 = 0; i0 < pw.nA && !empty; i0 += 1024 * R) {
+        const int ib = i0 + tid * R;
+        int j[R];
+        float best[R];
+        unsigned okbits = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = ib + r;
+            j[r] = -1;
+            best[r] = 0.0f;
+            if (i >= pw.nA) continue;
+            j[r] = j1[rf.fwd_off + i];
+            best[r] = k1[rf.fwd_off + i];
+            bool ok = j[r] >= 0;
             if (ok) {
                 if (rule.metric == 0) {
-                    ok = best > rule.min_score;
+                    ok = best[r] > rule.min_score;
                 } else {
-                    if (rule.max_dist >= 0.0f && best > rule.max_dist) ok = false;
+                    if (rule.max_dist >= 0.0f && best[r] > rule.max_dist) ok = false;
                     if (ok && rule.ratio_num > 0 && pw.nB >= 2) {
-                        const double lhs = (double)best * (double)rule.ratio_den * (double)rule.ratio_den;
+                        const double lhs = (double)best[r] * (double)rule.ratio_den * (double)rule.ratio_den;
                         const double rhs = (double)k2[rf.fwd_off + i] * (double)rule.ratio_num * (double)rule.ratio_num;
                         ok = lhs < rhs;
                     }
                 }
-                if (ok && rule.mutual && rf.bwd_off >= 0 && j1[rf.bwd_off + j] != i) ok = false;
+                if (ok && rule.mutual && rf.bwd_off >= 0 && j1[rf.bwd_off + j[r]] != i) ok = false;
             }
+            okbits |= (ok ? 1u : 0u) << r;
         }
-        const int slot = block_compact_slot(ok, wsum, &base_s);
-        if (ok) {
-            const size_t o = pw.out0_off + slot;
+        int slot = block_compact_range(__popc(okbits), wsum, &base_s);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (!((okbits >> r) & 1u)) continue;
+            const int i = ib + r;
+            const size_t o = pw.out0_off + slot++;
             out.slot_i0[o] = i;
-            out.slot_i1[o] = j;
-            if (out.slot_d) out.slot_d[o] = __float_as_int(best);
-            if (out.dense0) out.dense0[pw.out0_off + i] = j;
+            out.slot_i1[o] = j[r];
+            if (out.slot_d) out.slot_d[o] = __float_as_int(best[r]);
+            if (out.dense0) out.dense0[pw.out0_off + i] = j[r];
             // without the mutual check several rows may name one train row: report the lowest
-            if (out.dense1) atomicMin(&out.dense1[pw.out1_off + j], i);
+            if (out.dense1) atomicMin(&out.dense1[pw.out1_off + j[r]], i);
         }
     }
     __syncthreads();
@@ -64,13 +78,52 @@ void f32_accept_kernel(const SiftPair* __restrict__ pairs, const F32PairRef* __r
     if (out.dense1)
         for (int jj = tid; jj < pw.nB; jj += 1024)
             if (out.dense1[pw.out1_off + jj] == INT32_MAX) out.dense1[pw.out1_off + jj] = -1;
+    if (copy_dst) {
+        __syncthreads();   // this block wrote every word the segments name (or an earlier kernel did)
+        int base = 0;
+        for (int k = 0; k < copy_out.n; ++k) {
+            for (int i = tid; i < copy_out.count[k]; i += 1024) copy_dst[base + i] = copy_out.src[k][i];
+            base += copy_out.count[k];
+        }
+    }
 }
 
 void launch_f32_accept(const SiftPair* pairs, const F32PairRef* refs, int npairs, F32Rule rule,
-                       const int32_t* j1, const float* k1, const float* k2, SiftOutputs out, hipStream_t s)
+                       const int32_t* j1, const float* k1, const float* k2, SiftOutputs out, hipStream_t s,
+                       const WordSegments* copy_out, uint32_t* copy_dst)
 {
     if (npairs <= 0) return;
-    hipLaunchKernelGGL(f32_accept_kernel, dim3(npairs), dim3(1024), 0, s, pairs, refs, rule, j1, k1, k2, out);
+    const WordSegments none{};
+    hipLaunchKernelGGL(f32_accept_kernel, dim3(npairs), dim3(1024), 0, s, pairs, refs, rule, j1, k1, k2, out,
+                       copy_out && npairs == 1 ? *copy_out : none, copy_out && npairs == 1 ? copy_dst : nullptr);
+}
+
+// A submission's block of device records -- [256 bytes whose first word is the survivor-overflow flag][searches]
+// [pair records][references] -- written from kernel arguments instead of a copy from host memory, and the words the
+// splits of a search share cleared, in one launch: what a single-pair call queues in front of its searches (a copy
+// command and a fill command cost it two trips through the command processor, 17 us on the stream).
+__global__ __launch_bounds__(1024)
+void f32_plan_args_kernel(F32PlanArgs a, char* __restrict__ block, unsigned* __restrict__ shared_thr, int thr_words)
+{
+    const int tid = threadIdx.x;
+    if (tid < 64) reinterpret_cast<uint32_t*>(block)[tid] = 0;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&a);
+    uint32_t* probs = reinterpret_cast<uint32_t*>(block + 256);
+    constexpr int kProbWords = sizeof(CoarseProblem) / 4, kPairWords = sizeof(SiftPair) / 4, kRefWords = sizeof(F32PairRef) / 4;
+    const int nprob_words = a.nprobs * kProbWords;
+    for (int i = tid; i < nprob_words; i += 1024) probs[i] = src[i];
+    uint32_t* pair = reinterpret_cast<uint32_t*>(block + 256 + a.pbytes);
+    const uint32_t* pair_src = reinterpret_cast<const uint32_t*>(&a.pair);
+    if (tid < kPairWords) pair[tid] = pair_src[tid];
+    uint32_t* ref = reinterpret_cast<uint32_t*>(block + 256 + a.pbytes + a.pair_bytes);
+    const uint32_t* ref_src = reinterpret_cast<const uint32_t*>(&a.ref);
+    if (tid < kRefWords) ref[tid] = ref_src[tid];
+    for (int i = tid; i < thr_words; i += 1024) shared_thr[i] = 0;
+}
+
+void launch_f32_plan_args(const F32PlanArgs& a, char* block, unsigned* shared_thr, int thr_words, hipStream_t s)
+{
+    hipLaunchKernelGGL(f32_plan_args_kernel, dim3(1), dim3(1024), 0, s, a, block, shared_thr, thr_words);
 }
 
 __global__ __launch_bounds__(1024)

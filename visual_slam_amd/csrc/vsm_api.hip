@@ -118,6 +118,7 @@ struct vsm_ctx {
     // float sets: 0 = bf16 coarse pass + exact re-rank (exact kernel when a survivor list overflows), 1 = exact kernel only
     int f32_mode = 0, last_f32_path = -1;
     int f32_reverse = VSM_F32_REVERSE_AUTO, last_f32_reverse = -1;
+    bool f32_copied_out = false;   // the accept kernel of the last float submission copied the caller's words to pinned memory itself
     // u8 sets: 0 = the tile-minimum query pass for ratio-test submissions (packed form otherwise), 1 = packed form only
     int u8_mode = 0, last_u8_path = -1;
     // VSM_U8_AUTO only: after a tile-minimum submission most of whose rows needed the rescan pass (data full of
@@ -277,6 +278,11 @@ int plan_u8(vsm_ctx* c, const int32_t* pairs, int npairs, Plan& pl)
 
 struct RunOpts {
     bool want_dense = false, want_knn = false, want_dist = false, want_pack = true;
+    // float submissions of one pair: the device records travel as kernel arguments instead of a copy, and the accept
+    // kernel copies these words (device addresses; filled in by the caller once the buffers exist) to copy_dst
+    bool by_args = false;
+    std::function<void(WordSegments*)> copy_words;
+    uint32_t* copy_dst = nullptr;
     bool packed_only = false;   // keep to the packed query pass whatever the rule
 };
 
@@ -1092,6 +1098,7 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     c->R().u8_stats = false;
     c->timing_slot = c->rs;
     c->last_f32_reverse = nrev == 0 ? -1 : two_phase ? VSM_F32_REVERSE_CANDIDATES : VSM_F32_REVERSE_ALL;
+    c->f32_copied_out = false;
 
     // output slots first: the candidate lists in them are the query lists of the reverse searches
     const size_t n0 = std::max<size_t>(pl.out0, 1), n1 = std::max<size_t>(pl.out1, 1);
@@ -1163,7 +1170,21 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
         memcpy(h + 256 + pbytes + pair_bytes, pl.refs.data(), ref_bytes);
     }
     if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_probs.p, h, bytes, hipMemcpyHostToDevice, c->stream));
+    const bool by_args = o.by_args && npairs == 1 && nprobs >= 1 && nprobs <= 2 && !two_phase;
+    if (by_args) {
+        F32PlanArgs a{};
+        for (int k = 0; k < nprobs; ++k) a.probs[k] = pl.probs[k];
+        a.pair = pl.pairs[0];
+        a.ref = pl.refs[0];
+        a.nprobs = nprobs;
+        a.pbytes = (int32_t)pbytes;
+        a.pair_bytes = (int32_t)pair_bytes;
+        int thr_words = 0;
+        unsigned* thr = coarse_shared_thr(c->d_coarse.p, t1, &thr_words);
+        launch_f32_plan_args(a, c->d_probs.as<char>(), thr, thr_words, c->stream);
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->d_probs.p, h, bytes, hipMemcpyHostToDevice, c->stream));
+    }
     c->flag_dev = c->d_probs.as<int>();
     const CoarseProblem* d_probs = reinterpret_cast<const CoarseProblem*>(c->d_probs.as<char>() + 256);
     const SiftPair* d_pairs = reinterpret_cast<const SiftPair*>(c->d_probs.as<char>() + 256 + pbytes);
@@ -1178,7 +1199,8 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     float* k2 = c->d_knn2.as<float>();
     auto search = [&](const CoarseProblem* dp, const CoarseProblem* hp, int n, const CoarseTotals& t, bool lists) {
         if (n <= 0) return;
-        const bool finished = launch_bf16_batch(dp, n, pl.dim, t, j1, j2, k1, k2, c->d_coarse.p, c->flag_dev, c->stream, dot, lists);
+        const bool finished = launch_bf16_batch(dp, n, pl.dim, t, j1, j2, k1, k2, c->d_coarse.p, c->flag_dev, c->stream, dot, lists,
+                                                by_args);
         if (!dot && !finished) {
             int max_rows = 0;
             for (int i = 0; i < n; ++i) max_rows = std::max(max_rows, hp[i].pr.nA);
@@ -1204,7 +1226,10 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
         launch_f32_confirm(d_pairs, d_refs, npairs, j1, out, c->stream);
     } else {
         search(d_probs, pl.probs.data(), nprobs, t1, false);
-        launch_f32_accept(d_pairs, d_refs, npairs, rule, j1, k1, k2, out, c->stream);
+        WordSegments seg{};
+        if (o.copy_words && o.copy_dst && npairs == 1) o.copy_words(&seg);
+        launch_f32_accept(d_pairs, d_refs, npairs, rule, j1, k1, k2, out, c->stream, seg.n ? &seg : nullptr, o.copy_dst);
+        c->f32_copied_out = seg.n > 0;
     }
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));
@@ -1253,36 +1278,47 @@ int f32_single_pair_fast(vsm_ctx* c, const DescSet* A, const DescSet* B, int set
     F32Plan pl;
     int rc = plan_f32(c, one, 1, metric, p->mutual != 0, pl);
     if (rc) return rc;
+    // Everything the caller gets is copied, end to end, into one block of pinned host memory (it is mapped into the
+    // device's address space) by the accept kernel itself; one wait, no copy command and no kernel behind it.  The
+    // device records of the pair travel as kernel arguments.
+    const int take = std::min(std::max(cap, 0), A->n);   // a pair has at most nA matches
+    WordSegments seg{};
+    void* dst_host[8];
+    int flag_host = 0, cnt_host = 0;
+    auto list_words = [&](WordSegments* sg) {   // run once the device buffers exist
+        auto add = [&](const void* src, int words, void* host) {
+            if (words <= 0) return;
+            sg->src[sg->n] = static_cast<const uint32_t*>(src);
+            sg->count[sg->n] = words;
+            dst_host[sg->n] = host;
+            ++sg->n;
+        };
+        sg->n = 0;
+        add(c->flag_dev, 1, &flag_host);
+        add(c->d_counts.p, 1, &cnt_host);
+        if (idx0) add(c->d_slot0.p, take, idx0);
+        if (idx1) add(c->d_slot1.p, take, idx1);
+        if (dist) add(c->d_slotd.p, take, dist);
+        if (dense0) add(c->d_dense0.p, A->n, dense0);
+        if (dense1) add(c->d_dense1.p, B->n, dense1);
+        seg = *sg;
+    };
+    const size_t words = 2 + (size_t)take * ((idx0 ? 1 : 0) + (idx1 ? 1 : 0) + (dist ? 1 : 0)) + (dense0 ? (size_t)A->n : 0) +
+                         (dense1 ? (size_t)B->n : 0);
+    HIPCHK(c, c->h_gather.ensure(words * 4));
     RunOpts o;
     o.want_pack = false;
     o.want_dist = dist != nullptr;
     o.want_dense = dense0 != nullptr;
+    o.by_args = true;
+    o.copy_words = list_words;
+    o.copy_dst = c->h_gather.as<uint32_t>();
     if ((rc = run_f32_batch(c, pl, make_f32_rule(p, metric), o)) != VSM_OK) return rc;
-    // everything the caller gets goes into one device block, one copy to pinned memory, one wait
-    const int take = std::min(std::max(cap, 0), A->n);   // a pair has at most nA matches
-    WordSegments seg{};
-    void* dst_host[8];
-    auto add = [&](const void* src, int words, void* host) {
-        if (words <= 0) return;
-        seg.src[seg.n] = static_cast<const uint32_t*>(src);
-        seg.count[seg.n] = words;
-        dst_host[seg.n] = host;
-        ++seg.n;
-    };
-    int flag_host = 0, cnt_host = 0;
-    add(c->flag_dev, 1, &flag_host);
-    add(c->d_counts.p, 1, &cnt_host);
-    if (idx0) add(c->d_slot0.p, take, idx0);
-    if (idx1) add(c->d_slot1.p, take, idx1);
-    if (dist) add(c->d_slotd.p, take, dist);
-    if (dense0) add(c->d_dense0.p, A->n, dense0);
-    if (dense1) add(c->d_dense1.p, B->n, dense1);
-    size_t words = 0;
-    for (int k = 0; k < seg.n; ++k) words += (size_t)seg.count[k];
-    // the gather kernel writes straight into pinned host memory (it is mapped into the device's address space):
-    // no staging block and no copy command between the last kernel and the wait
-    HIPCHK(c, c->h_gather.ensure(words * 4));
-    launch_gather_words(seg, c->h_gather.as<uint32_t>(), c->stream);
+    if (!c->f32_copied_out) {   // (a pair without searches, or the two-stage mutual check: a kernel of its own copies)
+        WordSegments sg{};
+        list_words(&sg);
+        launch_gather_words(sg, c->h_gather.as<uint32_t>(), c->stream);
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     const uint32_t* got = c->h_gather.as<uint32_t>();

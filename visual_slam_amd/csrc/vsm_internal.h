@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_flags.h"
+#include "f32_kernels.h"
 #include <stdint.h>
 
 namespace vsm {
@@ -183,8 +184,29 @@ struct F32Rule {
 };
 // One block per pair; only nA, nB, out0_off and out1_off of SiftPair are read.  slot_d receives the
 // bits of the best key of every accepted row.
+// Several device arrays of 32-bit words copied end to end into one (so that one copy brings a small
+// result to the host).
+struct WordSegments {
+    const uint32_t* src[8];
+    int count[8];
+    int n;
+};
+// copy_out / copy_dst (one pair only, may be NULL): the block finally copies those device words end to end into
+// copy_dst, pinned host memory.
 void launch_f32_accept(const SiftPair* pairs, const F32PairRef* refs, int npairs, F32Rule rule,
-                       const int32_t* j1, const float* k1, const float* k2, SiftOutputs out, hipStream_t s);
+                       const int32_t* j1, const float* k1, const float* k2, SiftOutputs out, hipStream_t s,
+                       const WordSegments* copy_out = nullptr, uint32_t* copy_dst = nullptr);
+
+// The device records of a one-pair float submission as kernel arguments (see f32_plan_args_kernel): up to two
+// searches (forward, reverse), the pair record and its references, and where the last two go in the block.
+struct F32PlanArgs {
+    CoarseProblem probs[2];
+    SiftPair pair;
+    F32PairRef ref;
+    int32_t nprobs;
+    int32_t pbytes, pair_bytes;   // bytes the searches / the pair records take in the block (256-byte multiples)
+};
+void launch_f32_plan_args(const F32PlanArgs& a, char* block, unsigned* shared_thr, int thr_words, hipStream_t s);
 
 // Second half of a mutual check whose reverse searches ran on the candidates only: candidate k of a pair
 // (slot_i0 / slot_i1 / slot_d at out0_off + k, k < counts[pair]) stays when the reverse search of slot k
@@ -251,13 +273,6 @@ void launch_sift_verify(const SiftPair* pairs, int npairs, SiftItem* vitems, int
 void launch_sift_confirm(const SiftPair* pairs, int npairs, SiftCandidates cand, int mutual,
                          SiftOutputs out, hipStream_t s);
 // counts[npairs] -> offsets[npairs+1] (exclusive scan), then slots -> tight arrays
-// Several device arrays of 32-bit words copied end to end into one (so that one copy brings a small
-// result to the host).
-struct WordSegments {
-    const uint32_t* src[8];
-    int count[8];
-    int n;
-};
 void launch_gather_words(const WordSegments& seg, uint32_t* dst, hipStream_t s);
 
 // ---- geometric verification of putative matches -----------------------------------------
