@@ -388,6 +388,14 @@ int vsm_sample_rows_u8(vsm_ctx* ctx, const int32_t* sets, int nimg, int stride);
  * reference default of 20. */
 int vsm_mat_write_pmatch(const char* image1, const char* image2, int fc1, int fc2,
                          int nm, const int32_t* idx1, const int32_t* idx2, int reservation);
+/* MatchFile::multi_thread_mode (MatchFile.cpp:37, 221-231; switched by MatchFile.h:242-244): with it on the
+ * reference holds a mutex named after the .mat file from OpenMatchFile to CloseMatchFile.  Here: on != 0 makes every
+ * vsm_mat_* call of the process hold an advisory lock (flock) on a .mat file while it has it open, exclusive for the
+ * writers, shared for the readers, one file at a time, so that several processes (one per GPU, each matching its
+ * slice of the pair list) may write records of the same images with vsm_mat_write_pmatch / _fmatch / _ematch.  The
+ * files then hold every record, in the order the writers happened to arrive.  Not for vsm_mat_writer_*: it keeps
+ * directories in memory until it is closed and is for one process.  Returns the previous setting. */
+int vsm_mat_set_locking(int on);
 /* The same writer for long runs (SfM over thousands of pairs): every touched file's directory is
  * read once and kept in memory, at most max_open (<= 0: 256) descriptors stay open, directories are
  * written back by vsm_mat_writer_close.  The files end up byte for byte as repeated
@@ -411,10 +419,12 @@ int vsm_mat_get_match_count(const char* image, const char* other, int* nm, int* 
  * inlier index lists into the record of the pair in both images' files (F transposed and the rows
  * swapped in the second, as SetGeometryR and :735-746 do).  The pair's putative record must exist
  * (vsm_mat_write_pmatch).  Returns 1, 0 if a file has no such record, or a negative code.
- * NOT reproduced: the reference's re-allocation branch (MatchFile.cpp:690-719), taken when the record's
- * block cannot hold the inlier lists; there the reference moves the directory entry and leaves the
- * putative lists behind.  No record written by vsm_mat_write_pmatch reaches it with NF <= NM; a block
- * that is too small returns VSM_EUNSUPPORTED. */
+ * A record whose block cannot hold the inlier lists (a file from elsewhere, or nf above the record's NM; no record
+ * written by vsm_mat_write_pmatch with nf <= NM) goes through the re-allocation branch (MatchFile.cpp:690-719): it
+ * takes a larger block where it lies when it is the last of the file, the dead bytes behind it when those suffice,
+ * and otherwise moves to the end of the file.  In the last case the reference writes geometry and inliers at the new
+ * place and leaves NM and the putative lists at the old one (its own readers then find NM = 0); here they move with
+ * the record. */
 int vsm_mat_write_fmatch(const char* image1, const char* image2, int nf, const int32_t* idx1,
                          const int32_t* idx2, const float* F);
 /* MatchFile::WriteIMatch (MatchFile.cpp:643-748) with the whole two-view geometry: NF, F and the inlier

@@ -920,3 +920,86 @@ int orc_mat_get_pmatch(const char* image, const char* other, int fc_other,
     mt_close(&f);
     return nm;
 }
+
+/* MatchFile::WriteIMatch(image_match, reverse, NM = 0, tvg, inliers) (MatchFile.cpp:660-748) for the geometry
+ * WriteFMatch builds (:596-605: TwoViewGeometry(NF, F), MatchFile.h:85-92), one file.  Returns 1, or 0 when the file
+ * has no record of `other`.  The record on disk: version, the geometry as SetGeometry / SetGeometryR leave it
+ * (MatchFile.h:121-160; F transposed in the partner's file), everything else zero (the reference leaves the unset
+ * members of its stack object as they happen to be).
+ * One deviation, in the re-allocation branch (:690-719) when the record moves to the end of the file: the reference
+ * writes only the geometry and the inlier lists at the new place, so that NM and the putative lists stay behind and
+ * its readers find NM = 0; here the count and the lists move with the record. */
+static int mt_write_inliers(const char* image, const char* other, int reverse, int nf,
+                            const int32_t* row_a, const int32_t* row_b, const float* F)
+{
+    mt_file f;
+    if (!mt_open(&f, image, 1)) return -1;
+    if (!f.valid) { mt_close(&f); return 0; }
+    char rel[MT_MAX_PATH];
+    mt_relative_path(image, other, rel);                                                /* :666-668 */
+    mt_recloc* last = NULL;
+    mt_recloc* loc = mt_find(&f, rel, &last);
+    if (!loc) { mt_close(&f); return 0; }
+    int32_t nm = 0;
+    lseek(f.fd, loc->read_loc, SEEK_SET);                                               /* :676-680 */
+    if (read_all(f.fd, &nm, sizeof nm) != (ssize_t)sizeof nm || nm < 0) { mt_close(&f); return 0; }
+    const int szmin = (1 + (nm + nf) * 2) * (int)sizeof(int32_t) + (int)sizeof(mt_record);   /* :688 */
+    if (szmin > loc->block_size) {                                                      /* :690 */
+        const int bs = (int)sizeof(mt_record) + ((nm + nf) > 8 ? (nm + nf) : 8) * (int)sizeof(int32_t) * 4;
+        if (loc->block_size == 0 || loc == last) {                                      /* :695-699 */
+            loc->block_size = bs;
+        } else if (szmin > loc->block_size + loc->trash_size) {                         /* :700-706 */
+            int32_t* lists = (int32_t*)malloc(sizeof(int32_t) * (size_t)(2 * nm + 1));
+            lseek(f.fd, loc->read_loc + 4 + (off_t)sizeof(mt_record), SEEK_SET);
+            read_all(f.fd, lists, sizeof(int32_t) * (size_t)(2 * nm));
+            int* off = (int*)malloc(sizeof(int) * MT_MAX_RECORDS);
+            int n = mt_list(&f, off, MT_MAX_RECORDS), idx = -1;
+            for (int i = 0; i < n; ++i)
+                if ((mt_recloc*)(f.def + off[i]) == loc) idx = i;
+            free(off);
+            loc = mt_move_record_to_end(&f, idx);
+            if (!loc) { free(lists); mt_close(&f); return -2; }
+            loc->block_size = bs;
+            lseek(f.fd, loc->read_loc, SEEK_SET);                                       /* the deviation stated above */
+            write_all(f.fd, &nm, sizeof nm);
+            lseek(f.fd, (off_t)sizeof(mt_record), SEEK_CUR);
+            write_all(f.fd, lists, sizeof(int32_t) * (size_t)(2 * nm));
+            free(lists);
+        } else {                                                                        /* :707-711 */
+            loc->block_size += loc->trash_size;
+            loc->trash_size = 0;
+        }
+        lseek(f.fd, 0, SEEK_SET);                                                       /* :713-718 */
+        write_all(f.fd, &f.h, sizeof f.h);
+        write_all(f.fd, f.def, (size_t)f.h.definition_size);
+    }
+    mt_record rec;
+    memset(&rec, 0, sizeof rec);
+    rec.version = MR_VERSION_3;
+    rec.GE = 100.0f;
+    rec.NF = nf;
+    if (nf > 0)
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) rec.F[i][j] = reverse ? F[3 * j + i] : F[3 * i + j];
+    lseek(f.fd, loc->read_loc + (off_t)sizeof(int32_t), SEEK_SET);                      /* :683 / :717 */
+    write_all(f.fd, &rec, sizeof rec);                                                  /* :727 / :739 */
+    lseek(f.fd, (off_t)nm * 8, SEEK_CUR);                                               /* :728 / :741 */
+    if (nf > 0) {                                                                       /* :729-733 / :742-746 */
+        write_all(f.fd, reverse ? row_b : row_a, sizeof(int32_t) * (size_t)nf);
+        write_all(f.fd, reverse ? row_a : row_b, sizeof(int32_t) * (size_t)nf);
+    }
+    mt_close(&f);
+    return 1;
+}
+
+/* MatchFile::WriteFMatch (MatchFile.cpp:596-605) -> WriteIMatch (:643-658): the first image's file, then the second's */
+int orc_mat_write_fmatch(const char* image1, const char* image2, int nf, const int32_t* idx1, const int32_t* idx2,
+                         const float* F)
+{
+    if (!image1 || !image2 || !image1[0] || !image2[0]) return -1;
+    const int a = mt_write_inliers(image1, image2, 0, nf, idx1, idx2, F);
+    if (a < 0) return a;
+    const int b = mt_write_inliers(image2, image1, 1, nf, idx1, idx2, F);
+    if (b < 0) return b;
+    return a == 1 && b == 1;
+}

@@ -114,6 +114,9 @@ int orc_image_pairs(int n, int consecutive, const int32_t* discrete, int ndiscre
 int orc_mat_write_pmatch(const char* image1, const char* image2, int fc1, int fc2,
                          int nm, const int32_t* idx1, const int32_t* idx2, int reservation);
 /* MatchFile.cpp:856-895: returns NM (0 when absent or rejected). */
+/* MatchFile::WriteFMatch (MatchFile.cpp:596-605, 643-748), the record re-allocation of :690-719 included */
+int orc_mat_write_fmatch(const char* image1, const char* image2, int nf, const int32_t* idx1, const int32_t* idx2,
+                         const float* F);
 int orc_mat_get_pmatch(const char* image, const char* other, int fc_other,
                        int32_t* idx_this, int32_t* idx_other, int cap);
 

@@ -226,6 +226,13 @@ def mat_write_pmatch(image1, image2, fc1, fc2, idx1, idx2, reservation=0):
     return lib().orc_mat_write_pmatch(os.fsencode(image1), os.fsencode(image2), fc1, fc2, len(a), _p(a), _p(b), reservation)
 
 
+def mat_write_fmatch(image1, image2, idx1, idx2, F):
+    a = np.ascontiguousarray(idx1, np.int32)
+    b = np.ascontiguousarray(idx2, np.int32)
+    Fm = np.ascontiguousarray(F, np.float32).reshape(9)
+    return lib().orc_mat_write_fmatch(os.fsencode(image1), os.fsencode(image2), len(a), _p(a), _p(b), _p(Fm))
+
+
 def mat_get_pmatch(image, other, fc_other, cap=1 << 20):
     a = np.empty(cap, np.int32)
     b = np.empty(cap, np.int32)

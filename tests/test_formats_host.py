@@ -365,3 +365,113 @@ def test_resort_by_score_fixture():
     # and the list the exporter writes from it
     l0, l1, n = host.get_list_matching_pairs(nm2)
     assert n == 20 and len(l0.split()) == 20 and len(l1.split()) == 20
+
+
+def test_inlier_records_that_outgrow_their_block_match_oracle(tmp_path):
+    """WriteIMatch's re-allocation branch (MatchFile.cpp:690-719): inlier lists too long for a record's block, for the
+    last record of a file (larger block in place), a record in the middle and record 0 (both move to the end, NM and
+    the putative lists with them), and one that fits its block plus the dead bytes behind it.  Product and oracle
+    leave the same bytes in every file, the cached writer too, and every list reads back."""
+    rng = np.random.default_rng(77)
+    dirs = [tmp_path / name for name in ("p", "o", "w")]
+    for d in dirs:
+        d.mkdir()
+    n, fc = 6, 500
+    F = rng.standard_normal((3, 3)).astype(np.float32)
+    put, inl = {}, {}
+    steps = []
+    for b in range(1, n):
+        nm = 8 if b == 1 else 2 + b
+        steps.append(("p", 0, b, np.sort(rng.choice(fc, nm, replace=False)).astype(np.int32), rng.integers(0, fc, nm).astype(np.int32)))
+    for b, nf in ((5, 40), (2, 45), (3, 3), (1, 16), (2, 70), (4, 0)):
+        # i5: the last record; i2: the middle, moves (its predecessor i1 gains dead bytes); i3: fits; i1 (NM = 8): fits
+        # its block plus those dead bytes; i2 again, now the last record; i4: no inliers at all
+        steps.append(("f", 0, b, np.sort(rng.choice(fc, nf, replace=False)).astype(np.int32), rng.integers(0, fc, nf).astype(np.int32)))
+    steps.append(("f", 1, 0, np.arange(60, dtype=np.int32), np.arange(60, dtype=np.int32)[::-1].copy()))   # record 0 of file i1 moves
+    import ctypes as C
+    from visual_slam_amd import _binding as B
+    lib = B.lib()
+    w = lib.vsm_mat_writer_open(0, 2)
+    for kind, a, b, i0, i1 in steps:
+        pa, pb = ["i%d" % a, "i%d" % b]
+        if kind == "p":
+            host.write_pmatch(str(dirs[0] / pa), str(dirs[0] / pb), fc, fc, i0, i1)
+            assert orc.mat_write_pmatch(str(dirs[1] / pa), str(dirs[1] / pb), fc, fc, i0, i1) == 0
+            assert lib.vsm_mat_writer_put(w, str(dirs[2] / pa).encode(), str(dirs[2] / pb).encode(), fc, fc, len(i0), B._ptr(i0), B._ptr(i1)) == 0
+            put[(a, b)] = (i0, i1)
+        else:
+            assert host.write_fmatch(str(dirs[0] / pa), str(dirs[0] / pb), i0, i1, F) == 1
+            assert orc.mat_write_fmatch(str(dirs[1] / pa), str(dirs[1] / pb), i0, i1, F) == 1
+            Ff = np.ascontiguousarray(F.reshape(9))
+            assert lib.vsm_mat_writer_put_fmatch(w, str(dirs[2] / pa).encode(), str(dirs[2] / pb).encode(), len(i0), B._ptr(i0), B._ptr(i1), B._ptr(Ff)) == 1
+            inl[(min(a, b), max(a, b))] = (i0, i1, F) if a < b else (i1, i0, F.T)   # the first image's file holds F itself
+    assert lib.vsm_mat_writer_close(w) == 0
+    for k in range(n):
+        x, y, z = [(d / ("i%d.mat" % k)).read_bytes() for d in dirs]
+        assert x == y, "i%d.mat: product and oracle differ" % k
+        assert x == z, "i%d.mat: the cached writer differs" % k
+    for (a, b), (i0, i1) in put.items():
+        ga, gb = host.get_pmatch(str(dirs[0] / ("i%d" % a)), str(dirs[0] / ("i%d" % b)), fc)
+        np.testing.assert_array_equal(ga, i0)         # the putative lists moved with their record
+        np.testing.assert_array_equal(gb, i1)
+        gb2, ga2 = host.get_pmatch(str(dirs[0] / ("i%d" % b)), str(dirs[0] / ("i%d" % a)), fc)
+        np.testing.assert_array_equal(ga2, i0)
+        np.testing.assert_array_equal(gb2, i1)
+    for (a, b), (i0, i1, Fab) in inl.items():
+        nm, Fm, r0, r1 = host.get_imatch(str(dirs[0] / ("i%d" % a)), str(dirs[0] / ("i%d" % b)), fc)
+        assert nm == len(put[(a, b)][0])
+        np.testing.assert_array_equal(r0, i0)
+        np.testing.assert_array_equal(r1, i1)
+        if len(i0):
+            np.testing.assert_array_equal(Fm, Fab)
+        nm, Fm, r1b, r0b = host.get_imatch(str(dirs[0] / ("i%d" % b)), str(dirs[0] / ("i%d" % a)), fc)
+        np.testing.assert_array_equal(r0b, i0)
+        np.testing.assert_array_equal(r1b, i1)
+        if len(i0):
+            np.testing.assert_array_equal(Fm, Fab.T)
+    hdr = np.frombuffer((dirs[0] / "i1.mat").read_bytes()[:20], np.int32)
+    assert hdr[1] == 1 or hdr[3] >= 5680
+
+
+def _mat_writer_process(args):
+    """One of several processes that write putative and inlier records of pairs (0, k) into the same i0.mat."""
+    folder, ks, lock, start_at = args
+    import time
+    import numpy as np
+    from visual_slam_amd import _binding as B
+    from visual_slam_amd import host
+    B.lib().vsm_mat_set_locking(1 if lock else 0)
+    F = np.eye(3, dtype=np.float32)
+    while time.time() < start_at:      # all writers start together
+        pass
+    for k in ks:
+        i0 = np.arange(20 + k % 7, dtype=np.int32)
+        i1 = (i0 * 3 + k) % 1000
+        host.write_pmatch("%s/i0" % folder, "%s/i%d" % (folder, k), 1000, 1000, i0, i1.astype(np.int32))
+        host.write_fmatch("%s/i0" % folder, "%s/i%d" % (folder, k), i0[:5], i1[:5].astype(np.int32), F)
+    return len(ks)
+
+
+def test_processes_share_a_mat_file_under_locking(tmp_path):
+    """vsm_mat_set_locking (the counterpart of MatchFile::multi_thread_mode, MatchFile.cpp:221-231): four processes
+    write disjoint pairs that all involve image 0, so every one of them opens, extends and re-writes the directory of
+    i0.mat (which also fills up and doubles on the way); with the lock held from open to close no record is lost."""
+    import multiprocessing as mp
+    import time
+    nproc, per = 4, 150
+    start_at = time.time() + 3.0
+    jobs = [(str(tmp_path), list(range(1 + p, 1 + nproc * per, nproc)), True, start_at) for p in range(nproc)]
+    with mp.get_context("spawn").Pool(nproc) as pool:
+        assert sum(pool.map(_mat_writer_process, jobs)) == nproc * per
+    for k in range(1, 1 + nproc * per):
+        i0 = np.arange(20 + k % 7, dtype=np.int32)
+        i1 = ((i0 * 3 + k) % 1000).astype(np.int32)
+        ga, gb = host.get_pmatch(str(tmp_path / "i0"), str(tmp_path / ("i%d" % k)), 1000)
+        np.testing.assert_array_equal(ga, i0)
+        np.testing.assert_array_equal(gb, i1)
+        nm, Fm, r0, r1 = host.get_imatch(str(tmp_path / "i0"), str(tmp_path / ("i%d" % k)), 1000)
+        assert nm == len(i0)
+        np.testing.assert_array_equal(r0, i0[:5])
+        np.testing.assert_array_equal(r1, i1[:5])
+        gb2, ga2 = host.get_pmatch(str(tmp_path / ("i%d" % k)), str(tmp_path / "i0"), 1000)
+        np.testing.assert_array_equal(ga2, i0)

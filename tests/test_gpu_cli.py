@@ -237,9 +237,6 @@ def test_cli_explicit_pair_list(tmp_path):
         m0, _ = orc.match_dense_u8(imgs[a], imgs[b], orc.params((4, 5), True))
         expect.append(orc.matchtxt_record("%d.jpg" % a, "%d.jpg" % b, m0))
     assert open(out).read() == "".join(expect)
-    res = subprocess.run([CLI, "--sift-dir", str(tmp_path), "--num", "5", "--out", out, "--mat", "--shard", "0/2"],
-                         capture_output=True, text=True, timeout=120)
-    assert res.returncode == 2 and "--mat cannot be combined" in res.stderr   # slices share the .mat files
     for bad in ("0 9\n", "0 1\n2\n", "a b\n"):
         lst.write_text(bad)
         res = subprocess.run([CLI, "--sift-dir", str(tmp_path), "--num", "5", "--out", out, "--pairs-file", str(lst)],
@@ -284,3 +281,37 @@ def test_several_contexts_in_one_process_write_the_single_context_files(tmp_path
         assert one[name] == two[name], name
         assert one[name] == three[name], name
     assert len(one["matching"]) > 5000 and len(one["0.mat"]) > 5000
+
+
+def test_sharded_processes_write_the_same_mat_files_under_locks(tmp_path):
+    """--mat with --shard: three processes (all on GPU 0 here) match their slices of the pair list at the same time and
+    write putative and inlier records into the same .mat files, each update under a lock on the file: afterwards every
+    pair's records read back as the oracle's lists, from both images' files."""
+    import sys
+    nimg, n = 5, 300
+    kps, dess = synth.multi_view(nimg, n, seed=51)
+    for i in range(nimg):
+        loc = np.zeros((n, 5), np.float32)
+        loc[:, :2] = kps[i]
+        host.write_sift(str(tmp_path / ("%d.sift" % i)), loc, dess[i])
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "match_multi_gpu.py")
+    inl = str(tmp_path / "inliers.txt")
+    res = subprocess.run([sys.executable, tool, "--sift-dir", str(tmp_path), "--num", str(nimg), "--out", str(tmp_path / "m.txt"),
+                          "--devices", "0,0,0", "--batch", "2", "--mat", "--verify", "2.0", "--seed", "3", "--inlier-out", inl],
+                         capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stderr
+    ver = {(r[0], r[1]): r for r in _read_records(inl)}
+    for a in range(nimg):
+        for b in range(a + 1, nimg):
+            m0, _ = orc.match_dense_u8(dess[a], dess[b], orc.params((4, 5), True))
+            i0 = np.nonzero(m0 >= 0)[0]
+            ga, gb = host.get_pmatch(str(tmp_path / str(a)), str(tmp_path / str(b)), n)
+            np.testing.assert_array_equal(ga, i0)
+            np.testing.assert_array_equal(gb, m0[i0])
+            hb, ha = host.get_pmatch(str(tmp_path / str(b)), str(tmp_path / str(a)), n)
+            np.testing.assert_array_equal(ha, i0)
+            _, _, v0, v1 = ver[("%d.jpg" % a, "%d.jpg" % b)]
+            nm, Fm, r0, r1 = host.get_imatch(str(tmp_path / str(a)), str(tmp_path / str(b)), n)
+            assert nm == len(i0) and len(v0) > 50
+            np.testing.assert_array_equal(r0, v0)
+            np.testing.assert_array_equal(r1, v1)

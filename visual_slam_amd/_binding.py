@@ -121,6 +121,7 @@ SIGNATURES = {
     "vsm_shortlist_pairs": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong,
                                            C.c_void_p]),
     "vsm_mat_write_pmatch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "vsm_mat_set_locking": (C.c_int, [C.c_int]),
     "vsm_mat_writer_open": (C.c_void_p, [C.c_int, C.c_int]),
     "vsm_mat_writer_put": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vsm_mat_writer_close": (C.c_int, [C.c_void_p]),

@@ -9,10 +9,12 @@
 #include "../../include/vsm.h"
 
 #include <fcntl.h>
+#include <sys/file.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -708,6 +710,11 @@ std::string relative_name(const std::string& self, const std::string& other)
     return other;
 }
 
+// MatchFile::multi_thread_mode (MatchFile.cpp:37, :221-231): with it on, the reference takes a mutex named after
+// the file from OpenMatchFile to CloseMatchFile.  Here an advisory lock on the file itself (flock) takes that place:
+// exclusive for writers, shared for readers, held from open to close, across processes.
+std::atomic<int> g_mat_locking{0};
+
 // One image's match database, directory held in memory.
 class MatFile {
 public:
@@ -717,6 +724,11 @@ public:
         const std::string path = image + ".mat";
         fd_ = ::open(path.c_str(), for_write ? (O_CREAT | O_RDWR) : O_RDONLY, S_IRUSR | S_IWUSR);
         if (fd_ < 0) return false;
+        if (g_mat_locking.load(std::memory_order_relaxed)) {
+            int rc;
+            do rc = ::flock(fd_, for_write ? LOCK_EX : LOCK_SH); while (rc != 0 && errno == EINTR);
+            if (rc != 0) return false;
+        }
         MatHeader h;
         ssize_t got = read_at(0, &h, sizeof h);
         if (got == (ssize_t)sizeof h && h.definition_size > 0 && h.definition_buf >= h.definition_size &&
@@ -1009,6 +1021,11 @@ struct vsm_matwriter {
     }
 };
 
+extern "C" int vsm_mat_set_locking(int on)
+{
+    return g_mat_locking.exchange(on ? 1 : 0);
+}
+
 extern "C" vsm_matwriter* vsm_mat_writer_open(int reservation, int max_open)
 {
     vsm_matwriter* w = new vsm_matwriter();
@@ -1104,10 +1121,15 @@ extern "C" int vsm_mat_get_match_count(const char* image, const char* other, int
 namespace {
 
 // MatchFile::WriteIMatch(image_match, reverse, NM = 0, tvg, inliers), MatchFile.cpp:660-748, for the
-// geometry WriteFMatch builds (TwoViewGeometry(NF, F), MatchFile.h:85-92).  The record must exist and
-// have room, which every record written by WritePMatch has (block = 184 + max(NM, 8) * 24 bytes against
-// 188 + (NM + NF) * 8 needed, NF <= NM); the reference's re-allocation branch (:690-719) moves the
-// directory entry without the putative lists and is not reproduced.
+// geometry WriteFMatch builds (TwoViewGeometry(NF, F), MatchFile.h:85-92).  The record must exist.  Every record
+// written by WritePMatch has room (block = 184 + max(NM, 8) * 24 bytes against 188 + (NM + NF) * 8 needed, NF <= NM);
+// for one that has not (a file from elsewhere, or more inliers than putative matches) the re-allocation branch
+// (:690-719) runs: the last record of the file, or one without a block, gets a block of 184 + max(NM + NF, 8) * 16
+// bytes where it lies; one whose block and the dead bytes behind it suffice takes those; any other moves to the end
+// of the file as MoveRecordToEnd does (:422-453) with a block of that size.  In that last case the reference writes
+// only the geometry and the inlier lists at the new place and leaves the count and the putative lists behind, so that
+// its own readers (GetPMatch :877, GetIMatch :980-990) find NM = 0 there; here both are carried along, and the record
+// stays readable.  flush_dir = false leaves the changed directory in memory only (the cached writer).
 struct MatPose {   // NE, R, T, F1, F2 of TwoViewGeometry (MatchFile.h:68-83); ne = 0: none
     int ne = 0;
     const float* R = nullptr;
@@ -1116,15 +1138,39 @@ struct MatPose {   // NE, R, T, F1, F2 of TwoViewGeometry (MatchFile.h:68-83); n
 };
 
 int mat_put_inliers(MatFile& mf, const std::string& other, bool reverse, int nf,
-                    const int32_t* row_a, const int32_t* row_b, const float* F, const MatPose& pose = MatPose())
+                    const int32_t* row_a, const int32_t* row_b, const float* F, const MatPose& pose = MatPose(),
+                    bool flush_dir = true)
 {
-    const int idx = mf.find(relative_name(mf.image(), other));
+    int idx = mf.find(relative_name(mf.image(), other));
     if (idx < 0) return 0;
-    const MatRecLoc* loc = mf.rec(idx);
+    MatRecLoc* loc = mf.rec(idx);
     int32_t nm = 0;
     if (mf.read_at(loc->read_loc, &nm, 4) != 4 || nm < 0) return 0;
     const long long need = (1 + ((long long)nm + nf) * 2) * 4 + (long long)sizeof(MatRecord);
-    if (need > loc->block_size) return VSM_EUNSUPPORTED;
+    if (need > loc->block_size) {   // MatchFile.cpp:690-719
+        const long long fresh = (long long)sizeof(MatRecord) + std::max<long long>((long long)nm + nf, 8) * 16;
+        if (fresh > INT32_MAX) return VSM_EINVAL;
+        if (loc->block_size == 0 || idx == (int)mf.count() - 1) {
+            loc->block_size = (int32_t)fresh;
+        } else if (need > (long long)loc->block_size + loc->trash_size) {
+            // the count and the putative lists go with the record (the reference leaves them behind, see above)
+            std::vector<char> lists(4 + (size_t)nm * 8);
+            if (mf.read_at(loc->read_loc, lists.data(), 4) != 4 ||
+                mf.read_at((off_t)loc->read_loc + 4 + (off_t)sizeof(MatRecord), lists.data() + 4, (size_t)nm * 8) != (ssize_t)nm * 8)
+                return VSM_EIO;
+            mf.move_to_end(idx);
+            idx = (int)mf.count() - 1;
+            loc = mf.rec(idx);
+            loc->block_size = (int32_t)fresh;
+            if (!mf.write_at(loc->read_loc, lists.data(), 4) ||
+                !mf.write_at((off_t)loc->read_loc + 4 + (off_t)sizeof(MatRecord), lists.data() + 4, (size_t)nm * 8))
+                return VSM_EIO;
+        } else {
+            loc->block_size += loc->trash_size;
+            loc->trash_size = 0;
+        }
+        if (flush_dir && !mf.flush_directory()) return VSM_EIO;
+    }
     MatRecord rec;
     memset(&rec, 0, sizeof rec);
     rec.version = kRecVersion;
@@ -1169,12 +1215,20 @@ extern "C" int vsm_mat_write_fmatch(const char* image1, const char* image2, int 
 {
     if (!image1 || !image2 || !image1[0] || !image2[0] || nf < 0 || (nf > 0 && (!idx1 || !idx2 || !F))) return VSM_EINVAL;
     if (strlen(image1) + 5 > (size_t)kMaxPath || strlen(image2) + 5 > (size_t)kMaxPath) return VSM_EINVAL;
-    MatFile m1, m2;
-    if (!m1.open(image1, true)) return VSM_EIO;
-    const int a = mat_put_inliers(m1, image2, false, nf, idx1, idx2, F);
+    // one file at a time, as MatchFile.cpp:643-658 closes the first before it opens the second: with locking on,
+    // two writers that take the same two files in opposite order must not each hold one and wait for the other
+    int a, b;
+    {
+        MatFile m1;
+        if (!m1.open(image1, true)) return VSM_EIO;
+        a = mat_put_inliers(m1, image2, false, nf, idx1, idx2, F);
+    }
     if (a < 0) return a;
-    if (!m2.open(image2, true)) return VSM_EIO;
-    const int b = mat_put_inliers(m2, image1, true, nf, idx1, idx2, F);
+    {
+        MatFile m2;
+        if (!m2.open(image2, true)) return VSM_EIO;
+        b = mat_put_inliers(m2, image1, true, nf, idx1, idx2, F);
+    }
     if (b < 0) return b;
     return a == 1 && b == 1 ? 1 : 0;
 }
@@ -1185,10 +1239,10 @@ extern "C" int vsm_mat_writer_put_fmatch(vsm_matwriter* w, const char* image1, c
     if (!w || !image1 || !image2 || !image1[0] || !image2[0] || nf < 0 || (nf > 0 && (!idx1 || !idx2 || !F))) return VSM_EINVAL;
     if (w->failed) return VSM_EIO;
     MatFile* a = w->get(image1);
-    int ra = a ? mat_put_inliers(*a, image2, false, nf, idx1, idx2, F) : VSM_EIO;
+    int ra = a ? mat_put_inliers(*a, image2, false, nf, idx1, idx2, F, MatPose(), false) : VSM_EIO;
     if (ra < 0) return ra;
     MatFile* b = w->get(image2);
-    int rb = b ? mat_put_inliers(*b, image1, true, nf, idx1, idx2, F) : VSM_EIO;
+    int rb = b ? mat_put_inliers(*b, image1, true, nf, idx1, idx2, F, MatPose(), false) : VSM_EIO;
     if (rb < 0) return rb;
     return ra == 1 && rb == 1 ? 1 : 0;
 }
@@ -1207,12 +1261,18 @@ extern "C" int vsm_mat_write_ematch(const char* image1, const char* image2, int 
     if (strlen(image1) + 5 > (size_t)kMaxPath || strlen(image2) + 5 > (size_t)kMaxPath) return VSM_EINVAL;
     MatPose pose;
     pose.ne = ne; pose.R = R; pose.T = T; pose.f1 = f1; pose.f2 = f2;
-    MatFile m1, m2;
-    if (!m1.open(image1, true)) return VSM_EIO;
-    const int a = mat_put_inliers(m1, image2, false, nf, idx1, idx2, F, pose);
+    int a, b;
+    {
+        MatFile m1;
+        if (!m1.open(image1, true)) return VSM_EIO;
+        a = mat_put_inliers(m1, image2, false, nf, idx1, idx2, F, pose);
+    }
     if (a < 0) return a;
-    if (!m2.open(image2, true)) return VSM_EIO;
-    const int b = mat_put_inliers(m2, image1, true, nf, idx1, idx2, F, pose);
+    {
+        MatFile m2;
+        if (!m2.open(image2, true)) return VSM_EIO;
+        b = mat_put_inliers(m2, image1, true, nf, idx1, idx2, F, pose);
+    }
     if (b < 0) return b;
     return a == 1 && b == 1 ? 1 : 0;
 }
@@ -1227,10 +1287,10 @@ extern "C" int vsm_mat_writer_put_ematch(vsm_matwriter* w, const char* image1, c
     MatPose pose;
     pose.ne = ne; pose.R = R; pose.T = T; pose.f1 = f1; pose.f2 = f2;
     MatFile* a = w->get(image1);
-    int ra = a ? mat_put_inliers(*a, image2, false, nf, idx1, idx2, F, pose) : VSM_EIO;
+    int ra = a ? mat_put_inliers(*a, image2, false, nf, idx1, idx2, F, pose, false) : VSM_EIO;
     if (ra < 0) return ra;
     MatFile* b = w->get(image2);
-    int rb = b ? mat_put_inliers(*b, image1, true, nf, idx1, idx2, F, pose) : VSM_EIO;
+    int rb = b ? mat_put_inliers(*b, image1, true, nf, idx1, idx2, F, pose, false) : VSM_EIO;
     if (rb < 0) return rb;
     return ra == 1 && rb == 1 ? 1 : 0;
 }

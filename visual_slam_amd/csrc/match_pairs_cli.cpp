@@ -65,7 +65,8 @@ void usage()
             "  --ratio NUM/DEN       Lowe ratio, exact rational (default 4/5; 0/1 disables)\n"
             "  --max-dist D          keep matches with squared distance <= D\n"
             "  --no-mutual           skip the mutual-nearest-neighbour check\n"
-            "  --mat                 also write <DIR>/<i>.mat putative-match records\n"
+            "  --mat                 also write <DIR>/<i>.mat putative-match records (with --shard every process locks a\n"
+            "                        file while it updates it: all records arrive, in no fixed order within a file)\n"
             "  --verify PIXELS       geometric verification of every pair's matches (fundamental-matrix RANSAC,\n"
             "                        Sampson-distance threshold); with --mat the inlier records are written too\n"
             "  --samples N           RANSAC samples per pair (default 256); --seed S; --min-inliers K\n"
@@ -165,12 +166,6 @@ bool parse(int argc, char** argv, Options& o)
             }
         }
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
-    }
-    if (o.write_mat && o.nshards > 1) {
-        // every slice would update the records of the same <image>.mat files, and the writer keeps their
-        // directories in memory until it closes
-        fprintf(stderr, "--mat cannot be combined with --shard: write the .mat records from one process\n");
-        return false;
     }
     if (o.have_camera && !(o.verify > 0.0f)) {
         fprintf(stderr, "--camera needs --verify\n");
@@ -469,7 +464,11 @@ int main(int argc, char** argv)
     };
     const long long nbatches = (npairs + o.batch - 1) / o.batch;
 
-    vsm_matwriter* mw = o.write_mat ? vsm_mat_writer_open(o.num, 0) : nullptr;
+    // One process: the writer that keeps every file's directory in memory.  Several (--shard): every record is
+    // written through to the files under a lock per file, since the other processes update the same files.
+    const bool shared_mat = o.write_mat && o.nshards > 1;
+    if (shared_mat) vsm_mat_set_locking(1);
+    vsm_matwriter* mw = o.write_mat && !shared_mat ? vsm_mat_writer_open(o.num, 0) : nullptr;
     std::thread writer([&]() {
         for (long long next = 0; next < nbatches; ++next) {
             Batch* bp = nullptr;
@@ -492,8 +491,11 @@ int main(int argc, char** argv)
                 }
                 if (o.write_mat) {
                     const std::string p0 = o.sift_dir + "/" + std::to_string(ia), p1 = o.sift_dir + "/" + std::to_string(ib);
-                    const int rc = vsm_mat_writer_put(mw, p0.c_str(), p1.c_str(), count[ia], count[ib], nm,
-                                                      b.idx0.data() + b.off[k], b.idx1.data() + b.off[k]);
+                    const int rc = shared_mat
+                        ? vsm_mat_write_pmatch(p0.c_str(), p1.c_str(), count[ia], count[ib], nm, b.idx0.data() + b.off[k],
+                                               b.idx1.data() + b.off[k], o.num)
+                        : vsm_mat_writer_put(mw, p0.c_str(), p1.c_str(), count[ia], count[ib], nm,
+                                             b.idx0.data() + b.off[k], b.idx1.data() + b.off[k]);
                     if (rc < 0) {
                         fail("cannot write .mat for pair " + std::to_string(ia) + " " + std::to_string(ib));
                         break;
@@ -509,10 +511,17 @@ int main(int argc, char** argv)
                     }
                     if (o.write_mat) {
                         const std::string p0 = o.sift_dir + "/" + std::to_string(ia), p1 = o.sift_dir + "/" + std::to_string(ib);
-                        const int rc = o.have_camera
-                            ? vsm_mat_writer_put_ematch(mw, p0.c_str(), p1.c_str(), nin, q0, q1, b.F.data() + (size_t)k * 9, b.ne[k],
-                                                        b.R.data() + (size_t)k * 9, b.T.data() + (size_t)k * 3, o.camera[0], o.camera[0])
-                            : vsm_mat_writer_put_fmatch(mw, p0.c_str(), p1.c_str(), nin, q0, q1, b.F.data() + (size_t)k * 9);
+                        int rc;
+                        if (shared_mat)
+                            rc = o.have_camera
+                                ? vsm_mat_write_ematch(p0.c_str(), p1.c_str(), nin, q0, q1, b.F.data() + (size_t)k * 9, b.ne[k],
+                                                       b.R.data() + (size_t)k * 9, b.T.data() + (size_t)k * 3, o.camera[0], o.camera[0])
+                                : vsm_mat_write_fmatch(p0.c_str(), p1.c_str(), nin, q0, q1, b.F.data() + (size_t)k * 9);
+                        else
+                            rc = o.have_camera
+                                ? vsm_mat_writer_put_ematch(mw, p0.c_str(), p1.c_str(), nin, q0, q1, b.F.data() + (size_t)k * 9, b.ne[k],
+                                                            b.R.data() + (size_t)k * 9, b.T.data() + (size_t)k * 3, o.camera[0], o.camera[0])
+                                : vsm_mat_writer_put_fmatch(mw, p0.c_str(), p1.c_str(), nin, q0, q1, b.F.data() + (size_t)k * 9);
                         if (rc < 0) {
                             fail("cannot write inlier record for pair " + std::to_string(ia) + " " + std::to_string(ib));
                             break;
