@@ -659,7 +659,7 @@ def run_geom_verify(args, torch, dist, world, rank):
                      "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "geom_solve_kernel + geom_score_kernel + geom_emit_kernel",
                      "kernel_ms": kms,
                      "note": "f32 vector peak; kernel_ms brackets gather + RANSAC + final scoring; the eight-point "
-                             "solves (f64, LDS-resident) are not counted as work"},
+                             "solves (f64, register-resident) are not counted as work"},
     }
     if world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))

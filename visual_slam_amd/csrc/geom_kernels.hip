@@ -31,8 +31,7 @@
 // square root or compare in a fixed order: results do not depend on the grid, and the file is compiled
 // without floating-point contraction.
 //
-// Kernels: gather (match coordinates), solve (one sample per thread; the 8 x 9 systems sit in LDS, which
-// limits that kernel to one wave per SIMD, so it does nothing else), score (one sample per thread, all
+// Kernels: gather (match coordinates), solve (one sample per thread, its 8 x 9 system in registers), score (one sample per thread, all
 // matches of the pair, workgroup-wide choice of the winner), emit (one wave per pair: rank 2, refits,
 // final inlier list).
 #include <hip/hip_runtime.h>
@@ -86,12 +85,14 @@ __device__ __forceinline__ bool sampson_inlier(const float (&F)[9], const float4
     return e * e < t2 * den;
 }
 
-// The eight-point solve of one sample.  A lives in LDS, element (r, c) of thread t at
-// A[(r * 9 + c) * kGeomThreads + t] (rows and columns are swapped by run-time indices).
-__device__ bool solve_sample(double* __restrict__ A, const float4 (&pt)[8], float (&Fout)[9])
+// The eight-point solve of one sample.  The 8 x 9 system stays in registers (144 of them): every loop below has
+// compile-time bounds and is unrolled, and the rows and columns the pivot search picks at run time are brought into
+// place by conditional swaps (row r changes places with row k when r is the pivot's row, for every r > k), so no
+// element is ever addressed by a run-time index.  With the system in LDS, addressed by run-time indices, the kernel
+// was limited to one wave per SIMD by the 72 KB a workgroup needed and spent its time on LDS round trips.
+__device__ bool solve_sample(const float4 (&pt)[8], float (&Fout)[9])
 {
-    const int t = threadIdx.x;
-    auto at = [&](int r, int c) -> double& { return A[(r * 9 + c) * kGeomThreads + t]; };
+    double a[8][9];
     // Hartley normalisation per image
     double cx0 = 0, cy0 = 0, cx1 = 0, cy1 = 0;
 #pragma unroll
@@ -115,35 +116,62 @@ __device__ bool solve_sample(double* __restrict__ A, const float4 (&pt)[8], floa
     for (int k = 0; k < 8; ++k) {
         const double x0 = ((double)pt[k].x - cx0) * s0, y0 = ((double)pt[k].y - cy0) * s0;
         const double x1 = ((double)pt[k].z - cx1) * s1, y1 = ((double)pt[k].w - cy1) * s1;
-        at(k, 0) = x1 * x0; at(k, 1) = x1 * y0; at(k, 2) = x1;
-        at(k, 3) = y1 * x0; at(k, 4) = y1 * y0; at(k, 5) = y1;
-        at(k, 6) = x0;      at(k, 7) = y0;      at(k, 8) = 1.0;
+        a[k][0] = x1 * x0; a[k][1] = x1 * y0; a[k][2] = x1;
+        a[k][3] = y1 * x0; a[k][4] = y1 * y0; a[k][5] = y1;
+        a[k][6] = x0;      a[k][7] = y0;      a[k][8] = 1.0;
     }
-    // elimination with complete pivoting; perm: column j of the working matrix is unknown perm[j]
-    unsigned long long perm = 0x876543210ull;
+    // elimination with complete pivoting; perm[j]: the unknown that column j of the working matrix stands for
+    int perm[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) perm[j] = j;
+    bool singular = false;
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
         double best = 0.0;
         int pr = k, pc = k;
+#pragma unroll
         for (int r = k; r < 8; ++r)
+#pragma unroll
             for (int c = k; c < 9; ++c) {
-                const double v = fabs(at(r, c));
-                if (v > best) { best = v; pr = r; pc = c; }
+                const double v = fabs(a[r][c]);
+                const bool up = v > best;      // the first of equal magnitudes in this scan order stays
+                best = up ? v : best;
+                pr = up ? r : pr;
+                pc = up ? c : pc;
             }
-        if (!(best > 0.0)) return false;
-        if (pr != k)
-            for (int c = 0; c < 9; ++c) { const double tmp = at(k, c); at(k, c) = at(pr, c); at(pr, c) = tmp; }
-        if (pc != k) {
-            for (int r = 0; r < 8; ++r) { const double tmp = at(r, k); at(r, k) = at(r, pc); at(r, pc) = tmp; }
-            const unsigned long long a = (perm >> (4 * k)) & 15ull, b = (perm >> (4 * pc)) & 15ull;
-            perm &= ~((15ull << (4 * k)) | (15ull << (4 * pc)));
-            perm |= (b << (4 * k)) | (a << (4 * pc));
+        singular = singular || !(best > 0.0);
+#pragma unroll
+        for (int r = k + 1; r < 8; ++r) {      // rows k and pr change places
+            const bool sw = r == pr;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const double x = a[k][c], y = a[r][c];
+                a[k][c] = sw ? y : x;
+                a[r][c] = sw ? x : y;
+            }
         }
-        const double piv = at(k, k);
+#pragma unroll
+        for (int c = k + 1; c < 9; ++c) {      // columns k and pc change places, and the unknowns they stand for
+            const bool sw = c == pc;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const double x = a[r][k], y = a[r][c];
+                a[r][k] = sw ? y : x;
+                a[r][c] = sw ? x : y;
+            }
+            const int pk = perm[k], pcv = perm[c];
+            perm[k] = sw ? pcv : pk;
+            perm[c] = sw ? pk : pcv;
+        }
+        const double piv = a[k][k];
+#pragma unroll
         for (int r = k + 1; r < 8; ++r) {
-            const double f = at(r, k) / piv;
-            for (int c = k + 1; c < 9; ++c) at(r, c) -= f * at(k, c);
+            const double f = a[r][k] / piv;
+#pragma unroll
+            for (int c = k + 1; c < 9; ++c) a[r][c] -= f * a[k][c];
         }
     }
+    if (singular) return false;   // (a zero pivot makes the values above NaN or infinite; they are not used)
     // back substitution with the free unknown (working column 8) set to 1
     double x[9];
     x[8] = 1.0;
@@ -151,15 +179,20 @@ __device__ bool solve_sample(double* __restrict__ A, const float4 (&pt)[8], floa
     for (int k = 7; k >= 0; --k) {
         double s = 0.0;
 #pragma unroll
-        for (int c = k + 1; c < 9; ++c) s += at(k, c) * x[c];
-        x[k] = -s / at(k, k);
+        for (int c = k + 1; c < 9; ++c) s += a[k][c] * x[c];
+        x[k] = -s / a[k][k];
     }
-    // unknowns back in their places (row 0 of A is free now), unit norm
-#pragma unroll
-    for (int j = 0; j < 9; ++j) at(0, (int)((perm >> (4 * j)) & 15ull)) = x[j];
+    // unknowns back in their places, unit norm
     double f[9], nn = 0.0;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) { f[j] = at(0, j); nn += f[j] * f[j]; }
+    for (int u = 0; u < 9; ++u) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) v = perm[j] == u ? x[j] : v;
+        f[u] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) nn += f[j] * f[j];
     nn = sqrt(nn);
     if (!(nn > 0.0)) return false;
 #pragma unroll
@@ -194,8 +227,6 @@ __global__ __launch_bounds__(kGeomThreads)
 void geom_solve_kernel(const GeomPair* __restrict__ pairs, const float4* __restrict__ coords,
                        GeomRule rule, float* __restrict__ Fh)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* A = reinterpret_cast<double*>(smem);
     const GeomPair gp = pairs[blockIdx.y];
     const int h = blockIdx.x * kGeomThreads + threadIdx.x;
     if (h >= rule.hypotheses) return;
@@ -226,7 +257,7 @@ void geom_solve_kernel(const GeomPair* __restrict__ pairs, const float4* __restr
             float4 pt[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) pt[k] = pts[pick[k]];
-            ok = solve_sample(A, pt, F);
+            ok = solve_sample(pt, F);
         }
     }
 #pragma unroll
@@ -710,8 +741,6 @@ void launch_geom_pose(const GeomPair* pairs, int npairs, const float* cams, cons
 }
 
 
-size_t geom_lds_bytes() { return (size_t)72 * kGeomThreads * sizeof(double); }
-
 void launch_geom_verify(const GeomPair* pairs, int npairs, int max_matches, const int32_t* idx0, const int32_t* idx1,
                         const GeomRule& rule, float4* coords, float* Fh, float* Fbest, int32_t* best_count,
                         float* Fout, int32_t* counts, int32_t* slot_i0, int32_t* slot_i1, SiftPair* pack_pairs,
@@ -720,10 +749,8 @@ void launch_geom_verify(const GeomPair* pairs, int npairs, int max_matches, cons
     if (npairs <= 0) return;
     const int gx = std::max(1, std::min(64, (max_matches + 255) / 256));
     hipLaunchKernelGGL(geom_gather_kernel, dim3(gx, npairs), dim3(256), 0, s, pairs, npairs, idx0, idx1, coords);
-    static DeviceFlags attr_set;   // the attribute is per device
-    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(geom_solve_kernel), (int)geom_lds_bytes());
     hipLaunchKernelGGL(geom_solve_kernel, dim3((rule.hypotheses + kGeomThreads - 1) / kGeomThreads, npairs),
-                       dim3(kGeomThreads), geom_lds_bytes(), s, pairs, coords, rule, Fh);
+                       dim3(kGeomThreads), 0, s, pairs, coords, rule, Fh);
     hipLaunchKernelGGL(geom_score_kernel, dim3(npairs), dim3(kGeomScoreThreads), 0, s,
                        pairs, coords, rule, Fh, Fbest, best_count);
     hipLaunchKernelGGL(geom_emit_kernel, dim3(npairs), dim3(64), 0, s,

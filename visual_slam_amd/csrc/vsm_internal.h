@@ -291,7 +291,6 @@ struct GeomRule {
     int min_inliers;     // pairs with fewer inliers report none
     unsigned long long first_pair;   // sampling key of the call's first pair
 };
-size_t geom_lds_bytes();
 void launch_geom_verify(const GeomPair* pairs, int npairs, int max_matches, const int32_t* idx0, const int32_t* idx1,
                         const GeomRule& rule, float4* coords, float* Fh, float* Fbest, int32_t* best_count,
                         float* Fout, int32_t* counts, int32_t* slot_i0, int32_t* slot_i1, SiftPair* pack_pairs,
