@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates only the three files of the default workload (see tools/refresh_profiles.sh for the whole set).
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/prof
 mkdir -p $out

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Regenerates the measurements kept under profiles/ (run on the GPU box; results land in gpurun_out/prof/).
-# usage: tools/refresh_profiles.sh TAG      e.g. r02
+# usage: tools/refresh_profiles.sh TAG      e.g. r03
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/prof
 mkdir -p $out

@@ -547,6 +547,7 @@ class SlicedDatabase:
         rows = np.ascontiguousarray(rows, np.float32)
         n, dim = rows.shape if layout == LAYOUT_ROWS else rows.shape[::-1]
         self._check(self._l.vsm_dbq_load(self._h, _ptr(rows), n, dim, layout))
+        return self
 
     def slices(self):
         n = self._l.vsm_dbq_slices(self._h, None)

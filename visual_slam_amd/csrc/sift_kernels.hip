@@ -678,34 +678,47 @@ void sift_query_tile_kernel(const SiftPair* __restrict__ pairs, const SiftItem* 
 
 // Closes the gaps between the strips' candidate segments of the fused query pass: one workgroup per pair moves the
 // segments to the front in strip order (a segment only ever moves towards lower positions, and the segments before it
-// have moved already) and leaves the pair's candidate count.
+// have moved already) and leaves the pair's candidate count.  Candidates the resolve or rescan pass rejected (no row)
+// are dropped on the way: the mutual check then gathers train rows and runs matrix blocks for the accepted ones
+// only (on data full of duplicates every row is a candidate at first and nearly none is accepted).
 __global__ __launch_bounds__(kStripRows)
 void sift_gather_segments_kernel(const SiftPair* __restrict__ pairs, const int32_t* __restrict__ seg_counts,
                                  SiftCandidates cand)
 {
+    __shared__ int wsum[kStripRows / 64];
     const SiftPair pw = pairs[blockIdx.x];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int base = 0;
     const int nstrips = pw.nchunks > 0 ? pw.nstrips : 0;   // a pair with an empty set has no work items: nothing wrote its counts
     for (int sidx = 0; sidx < nstrips; ++sidx) {
         const int n = seg_counts[blockIdx.x * (kChunkCols / kStripRows) + sidx];
         const size_t src = pw.out0_off + (size_t)sidx * kStripRows + tid;
-        int i = 0, j = 0, d = 0;
+        int i = 0, j = -1, d = 0;
         if (tid < n) {
             i = cand.i0[src];
             j = cand.j1[src];
             d = cand.d1[src];
         }
-        __syncthreads();
-        if (tid < n) {
-            const size_t dst = pw.out0_off + base + tid;
+        const bool keep = j >= 0;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();   // every read of this segment is done, and the wave counts are in place
+        int before = __popcll(bal & ((1ull << lane) - 1ull)), total = 0;
+#pragma unroll
+        for (int w = 0; w < kStripRows / 64; ++w) {
+            const int c = wsum[w];
+            before += w < wave ? c : 0;
+            total += c;
+        }
+        if (keep) {
+            const size_t dst = pw.out0_off + base + before;
             cand.i0[dst] = i;
             cand.j1[dst] = j;
             cand.d1[dst] = d;
             cand.vbest[dst] = ~0ull;
         }
         __syncthreads();
-        base += n;
+        base += total;
     }
     if (tid == 0) cand.count[blockIdx.x] = base;
 }
