@@ -31,7 +31,7 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA
 HBM_PEAK_GBPS = 8000.0          # HBM3E
 
 
-def measured_traffic(kernel, summary="r02_traffic_sift_exhaustive.json"):
+def measured_traffic(kernel, summary="r03_traffic_sift_exhaustive.json"):
     """HBM bytes per launch of `kernel` from the committed hardware-counter passes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE over tools/traffic_probe.py or tools/db_query_probe.py at this workload's
     shape, folded by tools/pmc_summary.py); None when no such pass is in the tree."""
@@ -43,7 +43,7 @@ def measured_traffic(kernel, summary="r02_traffic_sift_exhaustive.json"):
         return None
 
 
-def measured_mfma_busy(kernel, summary="r02_mfma_utilisation.txt"):
+def measured_mfma_busy(kernel, summary="r03_mfma_utilisation.txt"):
     """Fraction of the elapsed SIMD cycles in which the matrix pipes were busy, from a committed counter
     pass (profiles/<summary>, written by tools/refresh_profiles.sh or tools/bf16_counters.sh: the kernel's name at the
     start of a line, the fraction after "SIMDs) = " on that line or the next); None when absent."""
@@ -383,10 +383,10 @@ def run_sift_exhaustive(args, torch, dist, world, rank):
                      "mfma_busy_frac": measured_mfma_busy("void vsm::sift_query_tile_kernel<true>")
                      if (nimg, nfeat, launch_pairs) == (1000, 8192, 2048) else None,
                      "mfma_busy_note": "matrix-pipe busy cycles / (elapsed cycles x SIMDs): a constant read from a committed "
-                                       "counter pass over the same submission shape (profiles/r02_mfma_utilisation.txt), "
+                                       "counter pass over the same submission shape (profiles/r03_mfma_utilisation.txt), "
                                        "not a measurement of this run",
                      "traffic_note": "HBM bytes per launch: a constant read from committed rocprofv3 --pmc passes over the same "
-                                     "submission shape (profiles/r02_probe1000_pmc_*.csv; FETCH_SIZE doubled as gfx950 needs), "
+                                     "submission shape (profiles/r03_probe1000_pmc_*.csv; FETCH_SIZE doubled as gfx950 needs), "
                                      "not a measurement of this run; algorithmic operand bytes per launch: %d"
                                      % (launch_pairs * 2 * nfeat * 128),
                      "kernel": "sift_query_tile_kernel" if m.last_u8_path() in (0, 2) else "sift_query_kernel", "kernel_ms": kms,
@@ -820,10 +820,10 @@ def run_db_query(args, torch, dist, world, rank):
                                  if world == 1 else None),
     }
     if world == 1 and m.last_f32_path() == 0:   # the counter passes were taken at this shape
-        out["roofline"]["traffic"] = measured_traffic("void vsm::bf16_coarse_kernel<256, false, false>", "r02_traffic_db_query.json")
+        out["roofline"]["traffic"] = measured_traffic("void vsm::bf16_coarse_kernel<256, false, false>", "r03_traffic_db_query.json")
         if out["roofline"]["traffic"]:
             out["roofline"]["traffic_note"] = ("HBM bytes per launch of the coarse kernel: a constant read from committed rocprofv3 "
-                                               "--pmc passes over the same search (profiles/r02_dbquery_pmc_*.csv), not a "
+                                               "--pmc passes over the same search (profiles/r03_dbquery_pmc_*.csv), not a "
                                                "measurement of this run")
             out["roofline"]["hbm_gb_per_s"] = out["roofline"]["traffic"] / (kms * 1e-3) / 1e9
             out["roofline"]["hbm_frac_of_peak"] = out["roofline"]["hbm_gb_per_s"] / HBM_PEAK_GBPS

@@ -134,7 +134,7 @@ def test_bench_finds_the_committed_counter_figures():
 
     sift = bench.measured_traffic("void vsm::sift_query_tile_kernel<true>")
     assert sift is not None and 1e9 < sift < 4.3e9          # below the algorithmic operand bytes of one launch
-    coarse = bench.measured_traffic("void vsm::bf16_coarse_kernel<256, false, false>", "r02_traffic_db_query.json")
+    coarse = bench.measured_traffic("void vsm::bf16_coarse_kernel<256, false, false>", "r03_traffic_db_query.json")
     assert coarse is not None and 5e8 < coarse < 3e9        # the bf16 database is 0.52 GB
     busy = bench.measured_mfma_busy("void vsm::sift_query_tile_kernel<true>")
     assert busy is not None and 0.5 < busy < 1.0
