@@ -59,6 +59,28 @@ def test_knn2_matches_oracle(matcher, n0, n1, dim, metric):
     _knn_check(matcher, a, b, metric)
 
 
+@pytest.mark.parametrize("n0,n1,dim", [(4100, 5000, 256), (4096, 4096, 128), (4200, 9000, 64)])
+@pytest.mark.parametrize("metric", [vsm.METRIC_DOT, vsm.METRIC_L2])
+def test_one_search_cut_into_many_splits(matcher, n0, n1, dim, metric):
+    """A few thousand queries against a few thousand rows: the search is cut into 16 to 32 splits to fill the chip and
+    the re-rank reads, per query, only the lists of the splits that can hold one of its two best rows."""
+    a, b = synth.superpoint_pair(n0, n1, dim, seed=7 + dim)
+    _knn_check(matcher, a, b, metric)
+
+
+@pytest.mark.parametrize("metric", [vsm.METRIC_DOT, vsm.METRIC_L2])
+def test_many_splits_with_thousands_of_equal_rows(matcher, metric):
+    """3000 copies of one row among 5000: for the queries equal to it every copy survives the coarse pass (lists longer
+    than one trip, more rows than a group's queue holds); the answer is still the two lowest indices."""
+    rng = np.random.default_rng(11)
+    a, b = synth.superpoint_pair(4100, 5000, 256, seed=12)
+    v = b[17].copy()
+    copies = rng.choice(5000, 3000, replace=False)
+    b[copies] = v
+    a[rng.choice(4100, 12, replace=False)] = v
+    _knn_check(matcher, a, b, metric)
+
+
 def test_knn2_non_unit_vectors_l2(matcher):
     rng = np.random.default_rng(5)
     a = rng.random((300, 256), dtype=np.float32) * 3

@@ -40,6 +40,7 @@
 // look at the candidates' rows.  Each lane of a staging wave fetches the 16-byte pieces of ITS row out of
 // whichever tile holds it; positions past the end of the list take the start value of a padding row (-inf).
 #include "f32_kernels.h"
+#include "vsm_internal.h"
 
 #include <math.h>
 
@@ -191,11 +192,18 @@ __device__ __forceinline__ float float_of_order_bits(unsigned e)
     return e == 0 ? -INFINITY : __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
 }
 
+// position of a workgroup in the list of (problem, split, strip) items: an XCD gets a contiguous run of them
+__device__ __forceinline__ int coarse_item_of_block()
+{
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+}
+
 template <int DIMP, bool TOP1, bool DBL>
-__global__ __launch_bounds__(kCoarseWaves * 64, 2)
-void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
-                        CoarsePart* __restrict__ part_all, uint2* __restrict__ lists_all, int* __restrict__ overflow,
-                        unsigned* __restrict__ shared_thr, int64_t out_rows0)
+__device__ __forceinline__ void coarse_body(const CoarseProblem& P, const int L,
+                                            CoarsePart* __restrict__ part_all, uint2* __restrict__ lists_all,
+                                            int* __restrict__ overflow, unsigned* __restrict__ shared_thr, int64_t out_rows0)
 {
     constexpr int S = DIMP / 16;             // k-steps (MFMAs) per tile
     constexpr int RB = kCoarseRB;
@@ -208,11 +216,6 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
     __shared__ __attribute__((aligned(16))) float s_init0[256];
     __shared__ __attribute__((aligned(16))) float s_init1[256];
 
-    const int nb = gridDim.x, bid = blockIdx.x;
-    const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
-    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int pi = find_problem(nprobs, L, [&](int i) { return probs[i].blk0; });
-    const CoarseProblem& P = probs[pi];
     const F32Problem pr = P.pr;
     const unsigned short* __restrict__ bfA = P.bfA;
     const unsigned short* __restrict__ bfB = P.bfB;
@@ -459,6 +462,44 @@ void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
     }
 }
 
+template <int DIMP, bool TOP1, bool DBL>
+__global__ __launch_bounds__(kCoarseWaves * 64, 2)
+void bf16_coarse_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
+                        CoarsePart* __restrict__ part_all, uint2* __restrict__ lists_all, int* __restrict__ overflow,
+                        unsigned* __restrict__ shared_thr, int64_t out_rows0)
+{
+    const int L = coarse_item_of_block();
+    const int pi = find_problem(nprobs, L, [&](int i) { return probs[i].blk0; });
+    coarse_body<DIMP, TOP1, DBL>(probs[pi], L, part_all, lists_all, overflow, shared_thr, out_rows0);
+}
+
+// The same for a one-pair call: the searches (and the pair's other device records) arrive as kernel arguments, so
+// nothing has to be copied or written before the first workgroup can start.  The first item also writes the records
+// into the submission's block in device memory, where the kernels behind this one read them.
+template <int DIMP, bool TOP1>
+__global__ __launch_bounds__(kCoarseWaves * 64, 2)
+void bf16_coarse_args_kernel(const F32PlanArgs a, char* __restrict__ block,
+                             CoarsePart* __restrict__ part_all, uint2* __restrict__ lists_all, int* __restrict__ overflow,
+                             unsigned* __restrict__ shared_thr, int64_t out_rows0)
+{
+    const int L = coarse_item_of_block();
+    if (L == 0) {
+        constexpr int kProbWords = sizeof(CoarseProblem) / 4, kPairWords = sizeof(SiftPair) / 4, kRefWords = sizeof(F32PairRef) / 4;
+        const int tid = threadIdx.x;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.probs[0]);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(block + 256);
+        for (int i = tid; i < a.nprobs * kProbWords; i += kCoarseWaves * 64) dst[i] = src[i];
+        const uint32_t* pair_src = reinterpret_cast<const uint32_t*>(&a.pair);
+        uint32_t* pair = reinterpret_cast<uint32_t*>(block + 256 + a.pbytes);
+        if (tid < kPairWords) pair[tid] = pair_src[tid];
+        const uint32_t* ref_src = reinterpret_cast<const uint32_t*>(&a.ref);
+        uint32_t* ref = reinterpret_cast<uint32_t*>(block + 256 + a.pbytes + a.pair_bytes);
+        if (tid < kRefWords) ref[tid] = ref_src[tid];
+    }
+    const CoarseProblem& P = a.nprobs > 1 && L >= a.probs[1].blk0 ? a.probs[1] : a.probs[0];
+    coarse_body<DIMP, TOP1, false>(P, L, part_all, lists_all, overflow, shared_thr, out_rows0);
+}
+
 // ---------------------------------------------------------------------------------
 // exact re-rank of the survivors
 // ---------------------------------------------------------------------------------
@@ -522,12 +563,11 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
     const int32_t* __restrict__ qlist = P.qlist;
     const int nq = qlist ? *P.qcount : pr.nA;
     const bool live = i < nq;
-    const int qrow = live ? (qlist ? qlist[i] : i) : 0;
-    if (live && lane * 4 < DIMP)
-        *reinterpret_cast<float4*>(&s_a[wave][lane * 4]) =
-            *reinterpret_cast<const float4*>(P.rowsA + (size_t)qrow * DIMP + lane * 4);
-    __syncthreads();   // the only workgroup barrier: everything below is per wave
-    if (!live) return;
+    if (!live) return;   // per wave: nothing below waits for another wave
+    const int qrow = qlist ? qlist[i] : i;
+    // the query row goes to LDS once the coarse records have been asked for: one trip to memory for both
+    float4 apiece = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (lane * 4 < DIMP) apiece = *reinterpret_cast<const float4*>(P.rowsA + (size_t)qrow * DIMP + lane * 4);
 
     volatile int* rows = s_rows[wave];
     const bool l2 = pr.metric == 1;
@@ -542,13 +582,21 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
 
     // final coarse runner-up over all splits and both lane halves
     float T1 = -INFINITY, T2 = -INFINITY;
-    int cnt_first = 0;   // list length of sublist `lane` (first chunk of 64 sublists)
+    int cnt_first = 0;             // list length of sublist `lane` (first chunk of 64 sublists)
+    float top_first = -INFINITY;   // and the largest key in it
     for (int sid = lane; sid < nsub; sid += 64) {
         const CoarsePart cp = part[sub_index(sid)];
         T2 = fmaxf(fmaxf(T2, cp.t2), fminf(T1, cp.t1));
         T1 = fmaxf(T1, cp.t1);
-        if (sid == lane) cnt_first = cp.count;
+        if (sid == lane) {
+            cnt_first = cp.count;
+            top_first = cp.t1;
+        }
     }
+    if (lane * 4 < DIMP) *reinterpret_cast<float4*>(&s_a[wave][lane * 4]) = apiece;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
         const float o1 = __shfl_xor(T1, m), o2 = __shfl_xor(T2, m);
@@ -596,7 +644,14 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
 
     for (int chunk = 0; chunk < nsub; chunk += 64) {
         const int sid = chunk + lane;
-        const int cnt = chunk == 0 ? cnt_first : (sid < nsub ? part[sub_index(sid)].count : 0);
+        // a sublist's largest key is its t1: below the final threshold none of its entries survives
+        int cnt = 0;
+        if (chunk == 0) {
+            cnt = top_first >= thr ? cnt_first : 0;
+        } else if (sid < nsub) {
+            const CoarsePart cp = part[sub_index(sid)];
+            cnt = cp.t1 >= thr ? cp.count : 0;
+        }
         int incl = cnt;   // inclusive prefix sum of the chunk's list lengths
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -660,165 +715,15 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
     }
 }
 
-// The same re-rank for submissions of many small problems (few sublists per query, millions of
-// queries): eight queries per wave.  A group of eight lanes reads the coarse results and the list
-// entries of one query and queues the rows that survive the final threshold; every group then scores the
-// rows of its own queue, one row per round: lane `sub` holds the same DIMP / 8 columns of the row as of the
-// query (registers; the whole row in one round trip to memory) and the k-ascending chain runs through the
-// group's lanes in order, handed on by a shuffle.  A query's row is only fetched when one of its lists holds
-// an entry (thresholded searches: most queries have none).  Results are bit-identical to bf16_rerank_kernel.
-constexpr int kGroupWaves = 4;
-constexpr int kGroupQueries = kGroupWaves * 8;   // queries per workgroup
-constexpr int kGroupQueue = 32;                  // surviving rows a group collects before they are scored
-
-template <int DIMP>
-__global__ __launch_bounds__(kGroupWaves * 64)
-void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
-                              const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
-                              int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
-                              float* __restrict__ k1_all, float* __restrict__ k2_all)
+// Results of a group's query, written by its first lane; `best` is the same in every lane of the group and lane
+// `sub` holds columns [sub * DIMP / 8, (sub + 1) * DIMP / 8) of the query row in areg.
+template <int Q>
+__device__ __forceinline__ void group_write_results(const CoarseProblem& P, const F32Problem& pr, int i, bool live,
+                                                    bool l2, int sub, int gbase, const float4 (&areg)[Q], const Best2& best,
+                                                    int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
+                                                    float* __restrict__ k1_all, float* __restrict__ k2_all)
 {
-    constexpr int Q = DIMP / 32;      // float4 pieces of a row per lane of a group
-    __shared__ int s_queue[kGroupWaves][8][kGroupQueue];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int sub = lane & 7, grp = lane >> 3, gbase = lane & ~7;
-    const CoarseProblem& P = probs[blockIdx.y];
-    const F32Problem pr = P.pr;
-    const int i = ((int)blockIdx.x * kGroupWaves + wave) * 8 + grp;   // query slot
-    const int32_t* __restrict__ qlist = P.qlist;
-    const int nslots = qlist ? *P.qcount : pr.nA;
-    if ((int)blockIdx.x * kGroupQueries >= nslots) return;   // the whole block is past the end of the query list
-    const bool live = i < nslots;
-    const int qrow = live ? (qlist ? qlist[i] : i) : 0;
-    volatile int* queue = s_queue[wave][grp];
-    const int nsub = P.nsplits * 2;
-    const CoarsePart* __restrict__ part = part_all + P.part_off;
-    const uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
-    auto sub_index = [&](int sid) { return ((size_t)(sid >> 1) * pr.nA_pad + i) * 2 + (sid & 1); };
-    // with a database list the entries name positions in it
-    const int32_t* __restrict__ dblist = P.dblist;
-    const int nrows_b = dblist ? *P.dbcount : pr.nB;
-
-    const bool l2 = pr.metric == 1;
-    const float na = live ? pr.nrmA[qrow] : 0.0f;
-    const float margin = coarse_margin(l2, na, *P.maxnormB_sq);
-    const float floorc = l2 ? -INFINITY : P.key_floor - 0.5f * margin;
-
-    // final coarse runner-up over all splits and both lane halves
-    float T1 = -INFINITY, T2 = -INFINITY;
-    int cnt_first = 0, cnt_any = 0;
-    if (live) {
-        for (int sid = sub; sid < nsub; sid += 8) {
-            const CoarsePart cp = part[sub_index(sid)];
-            T2 = fmaxf(fmaxf(T2, cp.t2), fminf(T1, cp.t1));
-            T1 = fmaxf(T1, cp.t1);
-            cnt_any |= cp.count;
-            if (sid == sub) cnt_first = cp.count;
-        }
-    }
-#pragma unroll
-    for (int m = 1; m < 8; m <<= 1) {
-        const float o1 = __shfl_xor(T1, m), o2 = __shfl_xor(T2, m);
-        T2 = fmaxf(fmaxf(T2, o2), fminf(T1, o1));
-        T1 = fmaxf(T1, o1);
-        cnt_any |= __shfl_xor(cnt_any, m);
-    }
-    const float thr = fmaxf((P.top1 ? T1 : T2) - margin, floorc);
-    // the query row is only ever read while a surviving row is scored: a query whose lists are all empty
-    // (a best score under the floor of a thresholded search) leaves it in memory
-    float4 areg[Q];   // columns [sub * DIMP / 8, (sub + 1) * DIMP / 8) of the group's query row
-#pragma unroll
-    for (int u = 0; u < Q; ++u) areg[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (cnt_any != 0) {
-        const float4* pa = reinterpret_cast<const float4*>(P.rowsA + (size_t)qrow * DIMP) + sub * Q;
-#pragma unroll
-        for (int u = 0; u < Q; ++u) areg[u] = pa[u];
-    }
-
-    Best2 best;   // the same in every lane of the group
-    best.s1 = -INFINITY; best.s2 = -INFINITY; best.r1 = -1; best.r2 = -1;
-    int nq = 0;   // rows in this group's queue (the same in every lane of the group)
-
-    // whole wave: every group scores the rows of its own queue, as many rounds as the longest queue has rows
-    auto score_all = [&]() {
-        int rounds = nq;
-#pragma unroll
-        for (int m = 8; m < 64; m <<= 1) rounds = max(rounds, __shfl_xor(rounds, m));
-        for (int q = 0; q < rounds; ++q) {
-            const int row = q < nq ? queue[q] : -1;   // -1: a padding row of the last tile, or no row this round
-            const bool act = row >= 0;
-            const float4* pb = reinterpret_cast<const float4*>(P.rowsB + (size_t)(act ? row : 0) * DIMP) + sub * Q;
-            float4 b[Q];
-#pragma unroll
-            for (int u = 0; u < Q; ++u) b[u] = pb[u];
-            const float nbr = l2 ? pr.nrmB[act ? row : 0] : 0.0f;
-            float d = 0.0f;
-#pragma unroll
-            for (int stage = 0; stage < 8; ++stage) {
-                if (sub == stage) {
-#pragma unroll
-                    for (int u = 0; u < Q; ++u) {
-                        d = fmaf(b[u].x, areg[u].x, d);
-                        d = fmaf(b[u].y, areg[u].y, d);
-                        d = fmaf(b[u].z, areg[u].z, d);
-                        d = fmaf(b[u].w, areg[u].w, d);
-                    }
-                }
-                const float handed = __shfl(d, gbase + stage);
-                if (sub == stage + 1) d = handed;
-                if (stage == 7) d = handed;   // the finished chain, in every lane of the group
-            }
-            const float sc = l2 ? fmaf(2.0f, d, -nbr) : d;
-            if (act && sc > -INFINITY) best2_insert(best, sc, row);
-        }
-        nq = 0;
-    };
-
-    for (int sid = 0; sid < nsub; ++sid) {
-        // list length: lane (sid & 7) of the group read it above when sid < 8
-        int cnt = __shfl(cnt_first, gbase + (sid & 7));
-        if (sid >= 8) cnt = live ? part[sub_index(sid)].count : 0;
-        const size_t mysub = sub_index(sid);
-        const int first_tile = (sid >> 1) * P.tiles_per_split;
-        for (int e0 = 0; __any(e0 < cnt); e0 += 32) {
-            unsigned ex[4];   // four entries per lane in flight
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = e0 + 8 * k + sub;
-                ex[k] = 0;
-                if (e < cnt) {
-                    const uint2 en = lists[list_slot(mysub, e)];
-                    if (__uint_as_float(en.y) >= thr) ex[k] = en.x;
-                }
-            }
-#pragma unroll 1
-            for (int k = 0; k < 4; ++k) {
-                unsigned m = (unsigned)(__ballot((ex[0] & 0xffffu) != 0) >> gbase) & 0xffu;   // this group's survivors
-                while (__any(m != 0)) {
-                    if (__any(nq + 16 > kGroupQueue)) score_all();
-                    if (m) {
-                        const int src = __ffs(m) - 1;
-                        m &= m - 1;
-                        const unsigned x = __shfl(ex[0], gbase + src);
-                        const unsigned bits = x & 0xffffu;
-                        // lane `sub` places the rows of registers sub and sub + 8
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int reg = sub + 8 * h;
-                            if ((bits >> reg) & 1u) {
-                                const int r = entry_row(x, reg, sid & 1, first_tile);
-                                queue[nq + __popc(bits & ((1u << reg) - 1u))] = r < nrows_b ? (dblist ? dblist[r] : r) : -1;
-                            }
-                        }
-                        nq += __popc(bits);
-                    }
-                }
-                ex[0] = ex[1]; ex[1] = ex[2]; ex[2] = ex[3]; ex[3] = 0;
-            }
-        }
-    }
-    score_all();
+    constexpr int DIMP = Q * 32;
     if (l2) {
         // L2 results in difference form, as f32_l2_finish_kernel states them: the two rows found by the key are
         // ordered by the k-ascending fmaf chain of (a[k] - b[k])^2 (lower row first when equal) and those
@@ -876,6 +781,190 @@ void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprob
         k1_all[o] = best.r1 < 0 ? -INFINITY : best.s1;
         k2_all[o] = best.r2 < 0 ? -INFINITY : best.s2;
     }
+}
+
+// The same re-rank for submissions of many small problems (few sublists per query, millions of
+// queries): eight queries per wave.  A group of eight lanes reads the coarse results and the list
+// entries of one query and queues the rows that survive the final threshold; every group then scores the
+// rows of its own queue, one row per round: lane `sub` holds the same DIMP / 8 columns of the row as of the
+// query (registers; the whole row in one round trip to memory) and the k-ascending chain runs through the
+// group's lanes in order, handed on by a shuffle.  A query's row is only fetched when one of its lists holds
+// an entry (thresholded searches: most queries have none).  Results are bit-identical to bf16_rerank_kernel.
+constexpr int kGroupWaves = 4;
+constexpr int kGroupQueries = kGroupWaves * 8;   // queries per workgroup
+constexpr int kGroupQueue = 32;                  // surviving rows a group collects before they are scored
+constexpr int kGroupMaxSub = 64;                 // sublists per query it can serve (a bit each in a 64-bit mask)
+static_assert(kCoarseCap < 65536, "list lengths travel as 16-bit words");
+
+template <int DIMP>
+__global__ __launch_bounds__(kGroupWaves * 64)
+void bf16_rerank_group_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
+                              const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
+                              int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
+                              float* __restrict__ k1_all, float* __restrict__ k2_all)
+{
+    constexpr int Q = DIMP / 32;      // float4 pieces of a row per lane of a group
+    __shared__ int s_queue[kGroupWaves][8][kGroupQueue];
+    __shared__ unsigned short s_count[kGroupWaves][8][kGroupMaxSub];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int sub = lane & 7, grp = lane >> 3, gbase = lane & ~7;
+    const CoarseProblem& P = probs[blockIdx.y];
+    const F32Problem pr = P.pr;
+    const int i = ((int)blockIdx.x * kGroupWaves + wave) * 8 + grp;   // query slot
+    const int32_t* __restrict__ qlist = P.qlist;
+    const int nslots = qlist ? *P.qcount : pr.nA;
+    if ((int)blockIdx.x * kGroupQueries >= nslots) return;   // the whole block is past the end of the query list
+    const bool live = i < nslots;
+    const int qrow = live ? (qlist ? qlist[i] : i) : 0;
+    volatile int* queue = s_queue[wave][grp];
+    const int nsub = P.nsplits * 2;
+    const CoarsePart* __restrict__ part = part_all + P.part_off;
+    const uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
+    auto sub_index = [&](int sid) { return ((size_t)(sid >> 1) * pr.nA_pad + i) * 2 + (sid & 1); };
+    // with a database list the entries name positions in it
+    const int32_t* __restrict__ dblist = P.dblist;
+    const int nrows_b = dblist ? *P.dbcount : pr.nB;
+
+    const bool l2 = pr.metric == 1;
+    const float na = live ? pr.nrmA[qrow] : 0.0f;
+    const float margin = coarse_margin(l2, na, *P.maxnormB_sq);
+    const float floorc = l2 ? -INFINITY : P.key_floor - 0.5f * margin;
+
+    // final coarse runner-up over all splits and both lane halves.  Lane `sub` reads the records of sublists
+    // sub, sub + 8, ... (all of them in flight at once) and keeps each one's largest key and list length.
+    float T1 = -INFINITY, T2 = -INFINITY;
+    float top[kGroupMaxSub / 8];
+    int len[kGroupMaxSub / 8];
+#pragma unroll
+    for (int k = 0; k < kGroupMaxSub / 8; ++k) {
+        const int sid = sub + 8 * k;
+        top[k] = -INFINITY;
+        len[k] = 0;
+        if (live && sid < nsub) {
+            const CoarsePart cp = part[sub_index(sid)];
+            top[k] = cp.t1;
+            len[k] = cp.count;
+            T2 = fmaxf(fmaxf(T2, cp.t2), fminf(T1, cp.t1));
+            T1 = fmaxf(T1, cp.t1);
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+        const float o1 = __shfl_xor(T1, m), o2 = __shfl_xor(T2, m);
+        T2 = fmaxf(fmaxf(T2, o2), fminf(T1, o1));
+        T1 = fmaxf(T1, o1);
+    }
+    const float thr = fmaxf((P.top1 ? T1 : T2) - margin, floorc);
+    // Only sublists whose largest key reaches the final threshold can hold a survivor (a search cut into many
+    // splits: one or two of them): a bit per such sublist, the same in every lane of the group.
+    unsigned long long todo = 0;
+#pragma unroll
+    for (int k = 0; k < kGroupMaxSub / 8; ++k) {
+        if (len[k] > 0 && top[k] >= thr) {
+            todo |= 1ull << (sub + 8 * k);
+            ((volatile unsigned short*)s_count[wave][grp])[sub + 8 * k] = (unsigned short)len[k];
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) todo |= __shfl_xor(todo, m);
+    // the query row is only ever read while a surviving row is scored: a query whose lists are all empty
+    // (a best score under the floor of a thresholded search) leaves it in memory
+    float4 areg[Q];   // columns [sub * DIMP / 8, (sub + 1) * DIMP / 8) of the group's query row
+#pragma unroll
+    for (int u = 0; u < Q; ++u) areg[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (todo != 0) {
+        const float4* pa = reinterpret_cast<const float4*>(P.rowsA + (size_t)qrow * DIMP) + sub * Q;
+#pragma unroll
+        for (int u = 0; u < Q; ++u) areg[u] = pa[u];
+    }
+
+    Best2 best;   // the same in every lane of the group
+    best.s1 = -INFINITY; best.s2 = -INFINITY; best.r1 = -1; best.r2 = -1;
+    int nq = 0;   // rows in this group's queue (the same in every lane of the group)
+
+    // whole wave: every group scores the rows of its own queue, as many rounds as the longest queue has rows
+    auto score_all = [&]() {
+        int rounds = nq;
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) rounds = max(rounds, __shfl_xor(rounds, m));
+        for (int q = 0; q < rounds; ++q) {
+            const int row = q < nq ? queue[q] : -1;   // -1: a padding row of the last tile, or no row this round
+            const bool act = row >= 0;
+            const float4* pb = reinterpret_cast<const float4*>(P.rowsB + (size_t)(act ? row : 0) * DIMP) + sub * Q;
+            float4 b[Q];
+#pragma unroll
+            for (int u = 0; u < Q; ++u) b[u] = pb[u];
+            const float nbr = l2 ? pr.nrmB[act ? row : 0] : 0.0f;
+            float d = 0.0f;
+#pragma unroll
+            for (int stage = 0; stage < 8; ++stage) {
+                if (sub == stage) {
+#pragma unroll
+                    for (int u = 0; u < Q; ++u) {
+                        d = fmaf(b[u].x, areg[u].x, d);
+                        d = fmaf(b[u].y, areg[u].y, d);
+                        d = fmaf(b[u].z, areg[u].z, d);
+                        d = fmaf(b[u].w, areg[u].w, d);
+                    }
+                }
+                const float handed = __shfl(d, gbase + stage);
+                if (sub == stage + 1) d = handed;
+                if (stage == 7) d = handed;   // the finished chain, in every lane of the group
+            }
+            const float sc = l2 ? fmaf(2.0f, d, -nbr) : d;
+            if (act && sc > -INFINITY) best2_insert(best, sc, row);
+        }
+        nq = 0;
+    };
+
+    // every group walks its own sublists: the groups of a wave are at different ones in the same iteration
+    while (__any(todo != 0)) {
+        const bool has = todo != 0;
+        const int sid = has ? __ffsll((long long)todo) - 1 : 0;
+        todo &= todo - 1;
+        const int cnt = has ? ((volatile unsigned short*)s_count[wave][grp])[sid] : 0;
+        const size_t mysub = sub_index(sid);
+        const int first_tile = (sid >> 1) * P.tiles_per_split;
+        for (int e0 = 0; __any(e0 < cnt); e0 += 32) {
+            unsigned ex[4];   // four entries per lane in flight
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + 8 * k + sub;
+                ex[k] = 0;
+                if (e < cnt) {
+                    const uint2 en = lists[list_slot(mysub, e)];
+                    if (__uint_as_float(en.y) >= thr) ex[k] = en.x;
+                }
+            }
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                unsigned m = (unsigned)(__ballot((ex[0] & 0xffffu) != 0) >> gbase) & 0xffu;   // this group's survivors
+                while (__any(m != 0)) {
+                    if (__any(nq + 16 > kGroupQueue)) score_all();
+                    if (m) {
+                        const int src = __ffs(m) - 1;
+                        m &= m - 1;
+                        const unsigned x = __shfl(ex[0], gbase + src);
+                        const unsigned bits = x & 0xffffu;
+                        // lane `sub` places the rows of registers sub and sub + 8
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int reg = sub + 8 * h;
+                            if ((bits >> reg) & 1u) {
+                                const int r = entry_row(x, reg, sid & 1, first_tile);
+                                queue[nq + __popc(bits & ((1u << reg) - 1u))] = r < nrows_b ? (dblist ? dblist[r] : r) : -1;
+                            }
+                        }
+                        nq += __popc(bits);
+                    }
+                }
+                ex[0] = ex[1]; ex[1] = ex[2]; ex[2] = ex[3]; ex[3] = 0;
+            }
+        }
+    }
+    score_all();
+    group_write_results<Q>(P, pr, i, live, l2, sub, gbase, areg, best, j1_all, j2_all, k1_all, k2_all);
 }
 
 // ---------------------------------------------------------------------------------
@@ -951,9 +1040,21 @@ unsigned* coarse_shared_thr(void* scratch, const CoarseTotals& t, int* words)
     return reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + part_bytes(t.sublists) + list_bytes(t.sublists));
 }
 
+template <int DIMP, bool TOP1>
+static void launch_coarse_args_t(const F32PlanArgs& a, char* block, int blocks, CoarsePart* part, uint2* lists,
+                                 int* overflow, unsigned* shared_thr, int64_t out_rows0, hipStream_t s)
+{
+    const int lds = 2 * kCoarseStepBytes;
+    static DeviceFlags attr_set;
+    ensure_dynamic_lds(attr_set, reinterpret_cast<const void*>(bf16_coarse_args_kernel<DIMP, TOP1>), lds);
+    hipLaunchKernelGGL((bf16_coarse_args_kernel<DIMP, TOP1>), dim3(blocks), dim3(kCoarseWaves * 64), lds, s,
+                       a, block, part, lists, overflow, shared_thr, out_rows0);
+}
+
 bool launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
                        int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow,
-                       hipStream_t s, bool top1, bool db_lists, bool thr_cleared)
+                       hipStream_t s, bool top1, bool db_lists, bool thr_cleared, const F32PlanArgs* by_args,
+                       char* args_block)
 {
     if (nprobs <= 0 || t.coarse_blocks <= 0) return false;
     CoarsePart* part = static_cast<CoarsePart*>(scratch);
@@ -962,6 +1063,14 @@ bool launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const 
     // the words the splits of a search share: 0 = nothing published yet
     if (shared_thr && t.max_nsplits > 1 && !thr_cleared) (void)hipMemsetAsync(shared_thr, 0, (size_t)(t.out_rows - t.out_rows0) * sizeof(unsigned), s);
     const int dimp = f32_dimp(dim);
+    if (by_args && !db_lists) {
+        if (dimp == 64) top1 ? launch_coarse_args_t<64, true>(*by_args, args_block, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s)
+                             : launch_coarse_args_t<64, false>(*by_args, args_block, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s);
+        else if (dimp == 128) top1 ? launch_coarse_args_t<128, true>(*by_args, args_block, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s)
+                                   : launch_coarse_args_t<128, false>(*by_args, args_block, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s);
+        else top1 ? launch_coarse_args_t<256, true>(*by_args, args_block, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s)
+                  : launch_coarse_args_t<256, false>(*by_args, args_block, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s);
+    } else
     if (dimp == 64) launch_coarse_d<64>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s, top1, db_lists);
     else if (dimp == 128) launch_coarse_d<128>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s, top1, db_lists);
     else launch_coarse_d<256>(d_probs, nprobs, t.coarse_blocks, part, lists, overflow, shared_thr, t.out_rows0, s, top1, db_lists);

@@ -124,9 +124,14 @@ size_t coarse_scratch_bytes(const CoarseTotals& t);
 // Returns true when L2 results are already ordered and reported in difference form (launch_f32_l2_finish is
 // then not needed), false when they are still keys.
 // thr_cleared: the caller has cleared the words the splits of a search share (coarse_shared_thr) itself.
+// by_args / args_block (one-pair calls, no database lists): the coarse kernel takes the searches from its own
+// arguments and writes the pair's records to args_block (the submission's block, d_probs = args_block + 256) for the
+// kernels behind it, instead of finding them there.
+struct F32PlanArgs;
 bool launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const CoarseTotals& t,
                        int32_t* j1, int32_t* j2, float* k1, float* k2, void* scratch, int* overflow,
-                       hipStream_t s, bool top1 = false, bool db_lists = false, bool thr_cleared = false);
+                       hipStream_t s, bool top1 = false, bool db_lists = false, bool thr_cleared = false,
+                       const F32PlanArgs* by_args = nullptr, char* args_block = nullptr);
 // Where those words lie in the scratch of a group of searches, and how many there are (0: no search is split).
 unsigned* coarse_shared_thr(void* scratch, const CoarseTotals& t, int* words);
 

@@ -14,7 +14,7 @@ namespace vsm {
 __global__ __launch_bounds__(1024)
 void f32_accept_kernel(const SiftPair* __restrict__ pairs, const F32PairRef* __restrict__ refs, F32Rule rule,
                        const int32_t* __restrict__ j1, const float* __restrict__ k1, const float* __restrict__ k2,
-                       SiftOutputs out, WordSegments copy_out, uint32_t* __restrict__ copy_dst)
+                       SiftOutputs out, WordSegments copy_out, uint32_t* __restrict__ copy_dst, F32LeaveClean clean)
 {
     __shared__ int wsum[16];
     __shared__ int base_s;
@@ -23,6 +23,8 @@ void f32_accept_kernel(const SiftPair* __restrict__ pairs, const F32PairRef* __r
     const F32PairRef rf = refs[blockIdx.x];
     const int tid = threadIdx.x;
     if (tid == 0) base_s = 0;
+    // the searches before this kernel are done with the words their splits shared: zero again for the next call
+    for (int i = tid; i < clean.thr_words; i += 1024) clean.thr[i] = 0;
     if (out.dense0)
         for (int i = tid; i < pw.nA; i += 1024) out.dense0[pw.out0_off + i] = -1;
     if (out.dense1)
@@ -86,44 +88,22 @@ void f32_accept_kernel(const SiftPair* __restrict__ pairs, const F32PairRef* __r
             base += copy_out.count[k];
         }
     }
+    if (clean.flag) {
+        __syncthreads();   // the flag has been copied out (it is one of the words above)
+        if (tid == 0) *clean.flag = 0;
+    }
 }
 
 void launch_f32_accept(const SiftPair* pairs, const F32PairRef* refs, int npairs, F32Rule rule,
                        const int32_t* j1, const float* k1, const float* k2, SiftOutputs out, hipStream_t s,
-                       const WordSegments* copy_out, uint32_t* copy_dst)
+                       const WordSegments* copy_out, uint32_t* copy_dst, const F32LeaveClean* clean)
 {
     if (npairs <= 0) return;
     const WordSegments none{};
+    const F32LeaveClean nothing{};
     hipLaunchKernelGGL(f32_accept_kernel, dim3(npairs), dim3(1024), 0, s, pairs, refs, rule, j1, k1, k2, out,
-                       copy_out && npairs == 1 ? *copy_out : none, copy_out && npairs == 1 ? copy_dst : nullptr);
-}
-
-// A submission's block of device records -- [256 bytes whose first word is the survivor-overflow flag][searches]
-// [pair records][references] -- written from kernel arguments instead of a copy from host memory, and the words the
-// splits of a search share cleared, in one launch: what a single-pair call queues in front of its searches (a copy
-// command and a fill command cost it two trips through the command processor, 17 us on the stream).
-__global__ __launch_bounds__(1024)
-void f32_plan_args_kernel(F32PlanArgs a, char* __restrict__ block, unsigned* __restrict__ shared_thr, int thr_words)
-{
-    const int tid = threadIdx.x;
-    if (tid < 64) reinterpret_cast<uint32_t*>(block)[tid] = 0;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(&a);
-    uint32_t* probs = reinterpret_cast<uint32_t*>(block + 256);
-    constexpr int kProbWords = sizeof(CoarseProblem) / 4, kPairWords = sizeof(SiftPair) / 4, kRefWords = sizeof(F32PairRef) / 4;
-    const int nprob_words = a.nprobs * kProbWords;
-    for (int i = tid; i < nprob_words; i += 1024) probs[i] = src[i];
-    uint32_t* pair = reinterpret_cast<uint32_t*>(block + 256 + a.pbytes);
-    const uint32_t* pair_src = reinterpret_cast<const uint32_t*>(&a.pair);
-    if (tid < kPairWords) pair[tid] = pair_src[tid];
-    uint32_t* ref = reinterpret_cast<uint32_t*>(block + 256 + a.pbytes + a.pair_bytes);
-    const uint32_t* ref_src = reinterpret_cast<const uint32_t*>(&a.ref);
-    if (tid < kRefWords) ref[tid] = ref_src[tid];
-    for (int i = tid; i < thr_words; i += 1024) shared_thr[i] = 0;
-}
-
-void launch_f32_plan_args(const F32PlanArgs& a, char* block, unsigned* shared_thr, int thr_words, hipStream_t s)
-{
-    hipLaunchKernelGGL(f32_plan_args_kernel, dim3(1), dim3(1024), 0, s, a, block, shared_thr, thr_words);
+                       copy_out && npairs == 1 ? *copy_out : none, copy_out && npairs == 1 ? copy_dst : nullptr,
+                       clean && npairs == 1 ? *clean : nothing);
 }
 
 __global__ __launch_bounds__(1024)

@@ -119,6 +119,14 @@ struct vsm_ctx {
     int f32_mode = 0, last_f32_path = -1;
     int f32_reverse = VSM_F32_REVERSE_AUTO, last_f32_reverse = -1;
     bool f32_copied_out = false;   // the accept kernel of the last float submission copied the caller's words to pinned memory itself
+    // What the last one-pair float call left zeroed on the device (overflow flag at the head of d_probs, the words the
+    // splits of its searches shared in d_coarse); anything else that uses those buffers voids it.
+    struct {
+        const void* flag = nullptr;
+        const void* thr = nullptr;
+        int thr_words = 0;
+        size_t probs_cap = 0, coarse_cap = 0;
+    } f32_clean;
     // u8 sets: 0 = the tile-minimum query pass for ratio-test submissions (packed form otherwise), 1 = packed form only
     int u8_mode = 0, last_u8_path = -1;
     // VSM_U8_AUTO only: after a tile-minimum submission most of whose rows needed the rescan pass (data full of
@@ -857,6 +865,7 @@ int queue_coarse(vsm_ctx* c, std::vector<CoarseProblem>& probs, int dim, size_t 
     HIPCHK(c, c->d_rrj.ensure(rows * 4));
     HIPCHK(c, c->d_knn1.ensure(rows * 4));
     HIPCHK(c, c->d_knn2.ensure(rows * 4));
+    c->f32_clean.flag = nullptr;
     HIPCHK(c, c->d_coarse.ensure(coarse_scratch_bytes(t)));
     HIPCHK(c, c->h_small.ensure(64));
     // block layout: [flag, 256 bytes][problems][extra]
@@ -1170,21 +1179,31 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
         memcpy(h + 256 + pbytes + pair_bytes, pl.refs.data(), ref_bytes);
     }
     if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev0, c->stream));
-    const bool by_args = o.by_args && npairs == 1 && nprobs >= 1 && nprobs <= 2 && !two_phase;
+    // One pair: its records travel as arguments of the coarse kernel, and the previous such call has left the flag
+    // and the shared words zeroed (its accept kernel does), so the searches are the first thing on the stream.
+    const bool by_args = o.by_args && npairs == 1 && nprobs >= 1 && nprobs <= 2 && !two_phase && t1.coarse_blocks > 0;
+    F32PlanArgs args{};
+    F32LeaveClean leave{};
     if (by_args) {
-        F32PlanArgs a{};
-        for (int k = 0; k < nprobs; ++k) a.probs[k] = pl.probs[k];
-        a.pair = pl.pairs[0];
-        a.ref = pl.refs[0];
-        a.nprobs = nprobs;
-        a.pbytes = (int32_t)pbytes;
-        a.pair_bytes = (int32_t)pair_bytes;
-        int thr_words = 0;
-        unsigned* thr = coarse_shared_thr(c->d_coarse.p, t1, &thr_words);
-        launch_f32_plan_args(a, c->d_probs.as<char>(), thr, thr_words, c->stream);
+        for (int k = 0; k < nprobs; ++k) args.probs[k] = pl.probs[k];
+        args.pair = pl.pairs[0];
+        args.ref = pl.refs[0];
+        args.nprobs = nprobs;
+        args.pbytes = (int32_t)pbytes;
+        args.pair_bytes = (int32_t)pair_bytes;
+        leave.thr = coarse_shared_thr(c->d_coarse.p, t1, &leave.thr_words);
+        leave.flag = c->d_probs.as<int>();
+        const bool clean = c->f32_clean.flag == c->d_probs.p && c->f32_clean.probs_cap == c->d_probs.cap &&
+                           (leave.thr_words == 0 || (c->f32_clean.thr == leave.thr && c->f32_clean.thr_words >= leave.thr_words &&
+                                                     c->f32_clean.coarse_cap == c->d_coarse.cap));
+        if (!clean) {
+            HIPCHK(c, hipMemsetAsync(c->d_probs.p, 0, 256, c->stream));
+            if (leave.thr_words) HIPCHK(c, hipMemsetAsync(leave.thr, 0, (size_t)leave.thr_words * sizeof(unsigned), c->stream));
+        }
     } else {
         HIPCHK(c, hipMemcpyAsync(c->d_probs.p, h, bytes, hipMemcpyHostToDevice, c->stream));
     }
+    c->f32_clean.flag = nullptr;
     c->flag_dev = c->d_probs.as<int>();
     const CoarseProblem* d_probs = reinterpret_cast<const CoarseProblem*>(c->d_probs.as<char>() + 256);
     const SiftPair* d_pairs = reinterpret_cast<const SiftPair*>(c->d_probs.as<char>() + 256 + pbytes);
@@ -1200,7 +1219,7 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     auto search = [&](const CoarseProblem* dp, const CoarseProblem* hp, int n, const CoarseTotals& t, bool lists) {
         if (n <= 0) return;
         const bool finished = launch_bf16_batch(dp, n, pl.dim, t, j1, j2, k1, k2, c->d_coarse.p, c->flag_dev, c->stream, dot, lists,
-                                                by_args);
+                                                by_args, by_args ? &args : nullptr, c->d_probs.as<char>());
         if (!dot && !finished) {
             int max_rows = 0;
             for (int i = 0; i < n; ++i) max_rows = std::max(max_rows, hp[i].pr.nA);
@@ -1228,8 +1247,18 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
         search(d_probs, pl.probs.data(), nprobs, t1, false);
         WordSegments seg{};
         if (o.copy_words && o.copy_dst && npairs == 1) o.copy_words(&seg);
-        launch_f32_accept(d_pairs, d_refs, npairs, rule, j1, k1, k2, out, c->stream, seg.n ? &seg : nullptr, o.copy_dst);
+        // the flag may only be zeroed by the kernel that also hands it to the caller
+        const bool leaves = by_args && seg.n > 0;
+        launch_f32_accept(d_pairs, d_refs, npairs, rule, j1, k1, k2, out, c->stream, seg.n ? &seg : nullptr, o.copy_dst,
+                          leaves ? &leave : nullptr);
         c->f32_copied_out = seg.n > 0;
+        if (leaves) {
+            c->f32_clean.flag = c->d_probs.p;
+            c->f32_clean.probs_cap = c->d_probs.cap;
+            c->f32_clean.thr = leave.thr;
+            c->f32_clean.thr_words = leave.thr_words;
+            c->f32_clean.coarse_cap = c->d_coarse.cap;
+        }
     }
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->R().ev1, c->stream));

@@ -191,13 +191,21 @@ struct WordSegments {
     int count[8];
     int n;
 };
+// What a one-pair call leaves zeroed for the next one, so that the next needs no fill command in front of its
+// searches: the words the splits of its searches shared, and the survivor-overflow flag once it has been copied out.
+struct F32LeaveClean {
+    unsigned* thr;
+    int thr_words;
+    int* flag;
+};
 // copy_out / copy_dst (one pair only, may be NULL): the block finally copies those device words end to end into
 // copy_dst, pinned host memory.
 void launch_f32_accept(const SiftPair* pairs, const F32PairRef* refs, int npairs, F32Rule rule,
                        const int32_t* j1, const float* k1, const float* k2, SiftOutputs out, hipStream_t s,
-                       const WordSegments* copy_out = nullptr, uint32_t* copy_dst = nullptr);
+                       const WordSegments* copy_out = nullptr, uint32_t* copy_dst = nullptr,
+                       const F32LeaveClean* clean = nullptr);
 
-// The device records of a one-pair float submission as kernel arguments (see f32_plan_args_kernel): up to two
+// The device records of a one-pair float submission as kernel arguments (see bf16_coarse_args_kernel): up to two
 // searches (forward, reverse), the pair record and its references, and where the last two go in the block.
 struct F32PlanArgs {
     CoarseProblem probs[2];
@@ -206,7 +214,6 @@ struct F32PlanArgs {
     int32_t nprobs;
     int32_t pbytes, pair_bytes;   // bytes the searches / the pair records take in the block (256-byte multiples)
 };
-void launch_f32_plan_args(const F32PlanArgs& a, char* block, unsigned* shared_thr, int thr_words, hipStream_t s);
 
 // Second half of a mutual check whose reverse searches ran on the candidates only: candidate k of a pair
 // (slot_i0 / slot_i1 / slot_d at out0_off + k, k < counts[pair]) stays when the reverse search of slot k
