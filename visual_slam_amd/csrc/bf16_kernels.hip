@@ -542,19 +542,16 @@ __device__ __forceinline__ void best2_insert(Best2& b, float sc, int row)
 // row), and the k-ascending fmaf chain runs through the group's lanes in order, handed on by a
 // shuffle.  The query row sits in LDS.
 template <int DIMP>
-__global__ __launch_bounds__(kRerankWaves * 64)
-void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
-                        const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
-                        int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
-                        float* __restrict__ k1_all, float* __restrict__ k2_all)
+__device__ __forceinline__ void rerank_body(const CoarseProblem& P,
+                                            const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
+                                            int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
+                                            float* __restrict__ k1_all, float* __restrict__ k2_all)
 {
     constexpr int Q = DIMP / 32;   // float4 pieces of a row per lane
     __shared__ int s_rows[kRerankWaves][64];
     __shared__ __attribute__((aligned(16))) float s_a[kRerankWaves][DIMP];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    // grid: x = block of kRerankWaves queries, y = problem (no search: a re-rank wave is short)
-    const CoarseProblem& P = probs[blockIdx.y];
     const F32Problem pr = P.pr;
     const int nsplits = P.nsplits;
     const CoarsePart* __restrict__ part = part_all + P.part_off;
@@ -713,6 +710,29 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
         k1_all[o] = best.r1 < 0 ? (l2 ? INFINITY : -INFINITY) : (l2 ? fmaxf(-best.s1 + na, 0.0f) : best.s1);
         k2_all[o] = best.r2 < 0 ? (l2 ? INFINITY : -INFINITY) : (l2 ? fmaxf(-best.s2 + na, 0.0f) : best.s2);
     }
+}
+
+template <int DIMP>
+__global__ __launch_bounds__(kRerankWaves * 64)
+void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
+                        const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
+                        int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
+                        float* __restrict__ k1_all, float* __restrict__ k2_all)
+{
+    // grid: x = block of kRerankWaves queries, y = problem (no search: a re-rank wave is short)
+    rerank_body<DIMP>(probs[blockIdx.y], part_all, lists_all, j1_all, j2_all, k1_all, k2_all);
+}
+
+// the searches as kernel arguments (one-pair calls, like bf16_coarse_args_kernel)
+template <int DIMP>
+__global__ __launch_bounds__(kRerankWaves * 64)
+void bf16_rerank_args_kernel(const F32PlanArgs a,
+                             const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
+                             int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
+                             float* __restrict__ k1_all, float* __restrict__ k2_all)
+{
+    const CoarseProblem& P = a.probs[blockIdx.y];
+    rerank_body<DIMP>(P, part_all, lists_all, j1_all, j2_all, k1_all, k2_all);
 }
 
 // Results of a group's query, written by its first lane; `best` is the same in every lane of the group and lane
@@ -1084,6 +1104,11 @@ bool launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const 
         if (dimp == 64) hipLaunchKernelGGL(bf16_rerank_group_kernel<64>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
         else if (dimp == 128) hipLaunchKernelGGL(bf16_rerank_group_kernel<128>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
         else hipLaunchKernelGGL(bf16_rerank_group_kernel<256>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
+    } else if (by_args) {
+        const dim3 grid(t.rerank_blocks, nprobs), block(kRerankWaves * 64);
+        if (dimp == 64) hipLaunchKernelGGL(bf16_rerank_args_kernel<64>, grid, block, 0, s, *by_args, part, lists, j1, j2, k1, k2);
+        else if (dimp == 128) hipLaunchKernelGGL(bf16_rerank_args_kernel<128>, grid, block, 0, s, *by_args, part, lists, j1, j2, k1, k2);
+        else hipLaunchKernelGGL(bf16_rerank_args_kernel<256>, grid, block, 0, s, *by_args, part, lists, j1, j2, k1, k2);
     } else {
         const dim3 grid(t.rerank_blocks, nprobs), block(kRerankWaves * 64);
         if (dimp == 64) hipLaunchKernelGGL(bf16_rerank_kernel<64>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);

@@ -14,13 +14,15 @@ namespace vsm {
 __global__ __launch_bounds__(1024)
 void f32_accept_kernel(const SiftPair* __restrict__ pairs, const F32PairRef* __restrict__ refs, F32Rule rule,
                        const int32_t* __restrict__ j1, const float* __restrict__ k1, const float* __restrict__ k2,
-                       SiftOutputs out, WordSegments copy_out, uint32_t* __restrict__ copy_dst, F32LeaveClean clean)
+                       SiftOutputs out, WordSegments copy_out, uint32_t* __restrict__ copy_dst, F32LeaveClean clean,
+                       F32PairArgs one)
 {
     __shared__ int wsum[16];
     __shared__ int base_s;
     constexpr int R = 4;
-    const SiftPair pw = pairs[blockIdx.x];
-    const F32PairRef rf = refs[blockIdx.x];
+    // a one-pair call hands the pair's records over as arguments: one trip to memory less
+    const SiftPair pw = one.given ? one.pair : pairs[blockIdx.x];
+    const F32PairRef rf = one.given ? one.ref : refs[blockIdx.x];
     const int tid = threadIdx.x;
     if (tid == 0) base_s = 0;
     // the searches before this kernel are done with the words their splits shared: zero again for the next call
@@ -92,18 +94,26 @@ void f32_accept_kernel(const SiftPair* __restrict__ pairs, const F32PairRef* __r
         __syncthreads();   // the flag has been copied out (it is one of the words above)
         if (tid == 0) *clean.flag = 0;
     }
+    if (copy_dst && one.done_seq) {
+        // every word is on its way to host memory before the word that says so
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(copy_dst + one.done_at, one.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 void launch_f32_accept(const SiftPair* pairs, const F32PairRef* refs, int npairs, F32Rule rule,
                        const int32_t* j1, const float* k1, const float* k2, SiftOutputs out, hipStream_t s,
-                       const WordSegments* copy_out, uint32_t* copy_dst, const F32LeaveClean* clean)
+                       const WordSegments* copy_out, uint32_t* copy_dst, const F32LeaveClean* clean,
+                       const F32PairArgs* one)
 {
     if (npairs <= 0) return;
     const WordSegments none{};
     const F32LeaveClean nothing{};
+    const F32PairArgs not_given{};
     hipLaunchKernelGGL(f32_accept_kernel, dim3(npairs), dim3(1024), 0, s, pairs, refs, rule, j1, k1, k2, out,
                        copy_out && npairs == 1 ? *copy_out : none, copy_out && npairs == 1 ? copy_dst : nullptr,
-                       clean && npairs == 1 ? *clean : nothing);
+                       clean && npairs == 1 ? *clean : nothing, one && npairs == 1 ? *one : not_given);
 }
 
 __global__ __launch_bounds__(1024)

@@ -5,6 +5,7 @@
 #include "f32_kernels.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -119,6 +120,8 @@ struct vsm_ctx {
     int f32_mode = 0, last_f32_path = -1;
     int f32_reverse = VSM_F32_REVERSE_AUTO, last_f32_reverse = -1;
     bool f32_copied_out = false;   // the accept kernel of the last float submission copied the caller's words to pinned memory itself
+    bool f32_watch_word = false;   // ... and writes a sequence number behind them when they are all on their way
+    uint32_t f32_seq = 0;
     // What the last one-pair float call left zeroed on the device (overflow flag at the head of d_probs, the words the
     // splits of its searches shared in d_coarse); anything else that uses those buffers voids it.
     struct {
@@ -289,6 +292,7 @@ struct RunOpts {
     // float submissions of one pair: the device records travel as kernel arguments instead of a copy, and the accept
     // kernel copies these words (device addresses; filled in by the caller once the buffers exist) to copy_dst
     bool by_args = false;
+    uint32_t done_at = 0, done_seq = 0;   // with copy_dst: the word that reports the copy as done, and what it will hold
     std::function<void(WordSegments*)> copy_words;
     uint32_t* copy_dst = nullptr;
     bool packed_only = false;   // keep to the packed query pass whatever the rule
@@ -1108,6 +1112,7 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
     c->timing_slot = c->rs;
     c->last_f32_reverse = nrev == 0 ? -1 : two_phase ? VSM_F32_REVERSE_CANDIDATES : VSM_F32_REVERSE_ALL;
     c->f32_copied_out = false;
+    c->f32_watch_word = false;
 
     // output slots first: the candidate lists in them are the query lists of the reverse searches
     const size_t n0 = std::max<size_t>(pl.out0, 1), n1 = std::max<size_t>(pl.out1, 1);
@@ -1249,8 +1254,17 @@ int run_f32_batch(vsm_ctx* c, F32Plan& pl, const F32Rule& rule, const RunOpts& o
         if (o.copy_words && o.copy_dst && npairs == 1) o.copy_words(&seg);
         // the flag may only be zeroed by the kernel that also hands it to the caller
         const bool leaves = by_args && seg.n > 0;
+        F32PairArgs one{};
+        if (by_args) {
+            one.pair = args.pair;
+            one.ref = args.ref;
+            one.given = 1;
+            one.done_at = o.done_at;
+            one.done_seq = seg.n > 0 ? o.done_seq : 0;
+        }
         launch_f32_accept(d_pairs, d_refs, npairs, rule, j1, k1, k2, out, c->stream, seg.n ? &seg : nullptr, o.copy_dst,
-                          leaves ? &leave : nullptr);
+                          leaves ? &leave : nullptr, by_args ? &one : nullptr);
+        c->f32_watch_word = by_args && seg.n > 0 && o.done_seq != 0;
         c->f32_copied_out = seg.n > 0;
         if (leaves) {
             c->f32_clean.flag = c->d_probs.p;
@@ -1334,8 +1348,13 @@ int f32_single_pair_fast(vsm_ctx* c, const DescSet* A, const DescSet* B, int set
     };
     const size_t words = 2 + (size_t)take * ((idx0 ? 1 : 0) + (idx1 ? 1 : 0) + (dist ? 1 : 0)) + (dense0 ? (size_t)A->n : 0) +
                          (dense1 ? (size_t)B->n : 0);
-    HIPCHK(c, c->h_gather.ensure(words * 4));
+    HIPCHK(c, c->h_gather.ensure((words + 1) * 4));
+    if (++c->f32_seq == 0) c->f32_seq = 1;
+    volatile uint32_t* done_word = c->h_gather.as<uint32_t>() + words;
+    *done_word = 0;
     RunOpts o;
+    o.done_at = (uint32_t)words;
+    o.done_seq = c->f32_seq;
     o.want_pack = false;
     o.want_dist = dist != nullptr;
     o.want_dense = dense0 != nullptr;
@@ -1348,7 +1367,21 @@ int f32_single_pair_fast(vsm_ctx* c, const DescSet* A, const DescSet* B, int set
         list_words(&sg);
         launch_gather_words(sg, c->h_gather.as<uint32_t>(), c->stream);
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // The accept kernel's last store is the sequence number behind the copied words: watching that word sees the
+    // result a few microseconds before the stream reports the kernel as finished.  Bounded: after 2 ms (a fault, a
+    // device lost) the stream is waited for, which reports what happened.
+    bool seen = false;
+    if (c->f32_watch_word) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(const_cast<const uint32_t*>(done_word), __ATOMIC_ACQUIRE) == c->f32_seq) {
+                seen = true;
+                break;
+            }
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    if (!seen) HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     const uint32_t* got = c->h_gather.as<uint32_t>();
     for (int k = 0; k < seg.n; ++k) {

@@ -198,12 +198,21 @@ struct F32LeaveClean {
     int thr_words;
     int* flag;
 };
+// A one-pair call's records as arguments of the accept kernel, and the word of copy_dst (index done_at) that
+// receives done_seq (non-zero) after every copied word: the caller may watch that word instead of waiting for
+// the stream.
+struct F32PairArgs {
+    SiftPair pair;
+    F32PairRef ref;
+    int32_t given;
+    uint32_t done_at, done_seq;
+};
 // copy_out / copy_dst (one pair only, may be NULL): the block finally copies those device words end to end into
 // copy_dst, pinned host memory.
 void launch_f32_accept(const SiftPair* pairs, const F32PairRef* refs, int npairs, F32Rule rule,
                        const int32_t* j1, const float* k1, const float* k2, SiftOutputs out, hipStream_t s,
                        const WordSegments* copy_out = nullptr, uint32_t* copy_dst = nullptr,
-                       const F32LeaveClean* clean = nullptr);
+                       const F32LeaveClean* clean = nullptr, const F32PairArgs* one = nullptr);
 
 // The device records of a one-pair float submission as kernel arguments (see bf16_coarse_args_kernel): up to two
 // searches (forward, reverse), the pair record and its references, and where the last two go in the block.
