@@ -508,6 +508,9 @@ void bf16_coarse_args_kernel(const F32PlanArgs a, char* __restrict__ block,
 // entries with coarse score >= T2 - margin, and scores those exactly with the k-ascending fmaf chain on
 // the plain row-major f32 copies of the two rows.
 constexpr int kRerankWaves = 4;
+// workgroups per CU the per-query re-rank is compiled for: 20 waves per CU (96 registers); with 24 and 32 the
+// spills cost more than the residency gives (16.3, 16.9, 21.5, 22.9 us for 5, 6, 7, 8 on a 4096 x 4096 pair)
+constexpr int kRerankMinBlocks = 5;
 
 // A list entry names up to 16 rows of one database tile: x = (tile - first tile of the split) << 16 |
 // bit per accumulator register, y = the largest coarse score among them.  Register `reg` of lane half
@@ -537,17 +540,18 @@ __device__ __forceinline__ void best2_insert(Best2& b, float sc, int row)
     }
 }
 
-// Exact scores of up to eight surviving rows at a time: eight lanes per row, lane `sub` of a group
-// holds columns [sub * DIMP/8, (sub + 1) * DIMP/8) of the row (one round trip to memory for the whole
-// row), and the k-ascending fmaf chain runs through the group's lanes in order, handed on by a
-// shuffle.  The query row sits in LDS.
+// Exact scores of up to four surviving rows at a time: sixteen lanes per row, lane `sub` of a group
+// holds columns [sub * DIMP/16, (sub + 1) * DIMP/16) of the row (one round trip to memory for the whole
+// row), and the k-ascending fmaf chain runs through the group's lanes in order.  The query row sits in LDS.
+// Few registers on purpose: a wave lives 7 us, most of it waiting for one of four trips to memory, so what a
+// 4096 x 4096 pair (8192 waves over both directions) costs is set by how many of them are resident at once.
 template <int DIMP>
 __device__ __forceinline__ void rerank_body(const CoarseProblem& P,
                                             const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
                                             int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
                                             float* __restrict__ k1_all, float* __restrict__ k2_all)
 {
-    constexpr int Q = DIMP / 32;   // float4 pieces of a row per lane
+    constexpr int Q = DIMP / 64;   // float4 pieces of a row per lane
     __shared__ int s_rows[kRerankWaves][64];
     __shared__ __attribute__((aligned(16))) float s_a[kRerankWaves][DIMP];
     const int lane = threadIdx.x & 63;
@@ -605,10 +609,13 @@ __device__ __forceinline__ void rerank_body(const CoarseProblem& P,
     Best2 best;
     best.s1 = -INFINITY; best.s2 = -INFINITY; best.r1 = -1; best.r2 = -1;
     int npending = 0;   // wave-uniform: rows waiting in `rows`
-    const int sub = lane & 7, grp = lane >> 3;
+    // Sixteen lanes per surviving row, four rows at a time: lane `sub` of a group holds columns
+    // [sub * DIMP/16, (sub + 1) * DIMP/16) of the row and of the query, and the k-ascending chain runs through the
+    // group's lanes in order, handed on by a move within the row of sixteen lanes.
+    const int sub = lane & 15, grp = lane >> 4;
     const float4* a4 = reinterpret_cast<const float4*>(&s_a[wave][0]) + sub * Q;
     auto flush = [&]() {
-        for (int base = 0; base < npending; base += 8) {
+        for (int base = 0; base < npending; base += 4) {
             const bool act = base + grp < npending;
             const int row = act ? rows[base + grp] : 0;
             const float4* pb = reinterpret_cast<const float4*>(P.rowsB + (size_t)row * DIMP) + sub * Q;
@@ -618,8 +625,11 @@ __device__ __forceinline__ void rerank_body(const CoarseProblem& P,
             const float nbr = pr.nrmB[row];
             float d = 0.0f;
 #pragma unroll
-            for (int stage = 0; stage < 8; ++stage) {
+            for (int stage = 0; stage < 16; ++stage) {
                 if (sub == stage) {
+                    // the query's columns are read from LDS here, by the lanes whose turn it is, and not kept in
+                    // registers over the sixteen stages (the statement below keeps the compiler from doing that)
+                    asm volatile("" ::: "memory");
 #pragma unroll
                     for (int u = 0; u < Q; ++u) {
                         const float4 a = a4[u];
@@ -629,12 +639,14 @@ __device__ __forceinline__ void rerank_body(const CoarseProblem& P,
                         d = fmaf(b[u].w, a.w, d);
                     }
                 }
-                const float handed = __shfl(d, (lane & ~7) + stage);
-                if (sub == stage + 1) d = handed;
-                if (stage == 7) d = handed;   // the finished chain, in every lane of the group
+                if (stage < 15) {
+                    // the value of the lane below (row_shr:1)
+                    const float handed = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(d), __float_as_int(d), 0x111, 0xf, 0xf, false));
+                    if (sub == stage + 1) d = handed;
+                }
             }
             const float sc = l2 ? fmaf(2.0f, d, -nbr) : d;
-            if (act && sub == 0 && sc > -INFINITY) best2_insert(best, sc, row);
+            if (act && sub == 15 && sc > -INFINITY) best2_insert(best, sc, row);   // the finished chain
         }
         npending = 0;
     };
@@ -713,7 +725,7 @@ __device__ __forceinline__ void rerank_body(const CoarseProblem& P,
 }
 
 template <int DIMP>
-__global__ __launch_bounds__(kRerankWaves * 64)
+__global__ __launch_bounds__(kRerankWaves * 64, kRerankMinBlocks)
 void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
                         const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
                         int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
@@ -725,7 +737,7 @@ void bf16_rerank_kernel(const CoarseProblem* __restrict__ probs, int nprobs,
 
 // the searches as kernel arguments (one-pair calls, like bf16_coarse_args_kernel)
 template <int DIMP>
-__global__ __launch_bounds__(kRerankWaves * 64)
+__global__ __launch_bounds__(kRerankWaves * 64, kRerankMinBlocks)
 void bf16_rerank_args_kernel(const F32PlanArgs a,
                              const CoarsePart* __restrict__ part_all, const uint2* __restrict__ lists_all,
                              int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,

@@ -1965,7 +1965,7 @@ extern "C" int vsm_recover_pose(vsm_ctx* c, const int32_t* xy_pairs, int npairs,
     int32_t* d_i1 = reinterpret_cast<int32_t*>(w); w += b_idx;
     float* d_T = reinterpret_cast<float*>(w); w += b_T;
     int32_t* d_ne = reinterpret_cast<int32_t*>(w); w += b_ne;
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // d_geom may still serve a queued verification
+    // d_geom may still serve a queued verification: that work lies on this same stream, before these copies
     HIPCHK(c, hipMemcpyAsync(d_gp, gp.data(), sizeof(GeomPair) * npairs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_cam, cameras, (size_t)npairs * 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_F, F, (size_t)npairs * 36, hipMemcpyHostToDevice, c->stream));
