@@ -503,14 +503,15 @@ void bf16_coarse_args_kernel(const F32PlanArgs a, char* __restrict__ block,
 // ---------------------------------------------------------------------------------
 // exact re-rank of the survivors
 // ---------------------------------------------------------------------------------
-// One wave per query.  Lane l first folds the coarse top-2 of sublist l into the query's final coarse
-// runner-up T2, then the wave walks the concatenated survivor lists 64 entries at a time, keeps the
-// entries with coarse score >= T2 - margin, and scores those exactly with the k-ascending fmaf chain on
-// the plain row-major f32 copies of the two rows.
+// Half a wave per query.  Lane l of the half first folds the coarse top-2 of sublist l into the query's final coarse
+// runner-up T2, then the half walks the concatenated survivor lists of the sublists that can hold a survivor
+// 32 entries at a time, keeps the entries with coarse score >= T2 - margin, and scores those exactly with the
+// k-ascending fmaf chain on the plain row-major f32 copies of the two rows.
 constexpr int kRerankWaves = 4;
 // workgroups per CU the per-query re-rank is compiled for: 20 waves per CU (96 registers); with 24 and 32 the
 // spills cost more than the residency gives (16.3, 16.9, 21.5, 22.9 us for 5, 6, 7, 8 on a 4096 x 4096 pair)
 constexpr int kRerankMinBlocks = 5;
+constexpr int kRerankPerWave = 2;   // queries per wave: one per half
 
 // A list entry names up to 16 rows of one database tile: x = (tile - first tile of the split) << 16 |
 // bit per accumulator register, y = the largest coarse score among them.  Register `reg` of lane half
@@ -551,26 +552,34 @@ __device__ __forceinline__ void rerank_body(const CoarseProblem& P,
                                             int32_t* __restrict__ j1_all, int32_t* __restrict__ j2_all,
                                             float* __restrict__ k1_all, float* __restrict__ k2_all)
 {
-    constexpr int Q = DIMP / 64;   // float4 pieces of a row per lane
-    __shared__ int s_rows[kRerankWaves][64];
-    __shared__ __attribute__((aligned(16))) float s_a[kRerankWaves][DIMP];
+    constexpr int Q = DIMP / 64;                        // float4 pieces of a row per lane of a sixteen-lane group
+    constexpr int AP = DIMP > 128 ? DIMP / 128 : 1;     // float4 pieces of the query row a lane fetches
+    __shared__ int s_rows[kRerankWaves][2][32];
+    __shared__ __attribute__((aligned(16))) float s_a[kRerankWaves][2][DIMP];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5, l5 = lane & 31;         // a query per half wave
     const F32Problem pr = P.pr;
     const int nsplits = P.nsplits;
     const CoarsePart* __restrict__ part = part_all + P.part_off;
     const uint2* __restrict__ lists = lists_all + P.part_off * kCoarseCap;
-    const int i = (int)blockIdx.x * kRerankWaves + wave;   // query slot
+    const int i0 = ((int)blockIdx.x * kRerankWaves + wave) * kRerankPerWave;
+    const int i = i0 + half;                            // query slot
     const int32_t* __restrict__ qlist = P.qlist;
     const int nq = qlist ? *P.qcount : pr.nA;
+    if (i0 >= nq) return;   // per wave: nothing below waits for another wave
     const bool live = i < nq;
-    if (!live) return;   // per wave: nothing below waits for another wave
-    const int qrow = qlist ? qlist[i] : i;
+    const int qrow = live ? (qlist ? qlist[i] : i) : 0;
     // the query row goes to LDS once the coarse records have been asked for: one trip to memory for both
-    float4 apiece = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (lane * 4 < DIMP) apiece = *reinterpret_cast<const float4*>(P.rowsA + (size_t)qrow * DIMP + lane * 4);
+    float4 apiece[AP];
+#pragma unroll
+    for (int k = 0; k < AP; ++k) {
+        const int piece = l5 + 32 * k;
+        apiece[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (live && piece * 4 < DIMP) apiece[k] = *reinterpret_cast<const float4*>(P.rowsA + (size_t)qrow * DIMP + piece * 4);
+    }
 
-    volatile int* rows = s_rows[wave];
+    volatile int* rows = s_rows[wave][half];
     const bool l2 = pr.metric == 1;
     const float na = pr.nrmA[qrow];
     const float margin = coarse_margin(l2, na, *P.maxnormB_sq);
@@ -581,25 +590,30 @@ __device__ __forceinline__ void rerank_body(const CoarseProblem& P,
     const int32_t* __restrict__ dblist = P.dblist;
     const int nrows_b = dblist ? *P.dbcount : pr.nB;
 
-    // final coarse runner-up over all splits and both lane halves
+    // final coarse runner-up over all splits and both lane halves of the coarse kernel
     float T1 = -INFINITY, T2 = -INFINITY;
-    int cnt_first = 0;             // list length of sublist `lane` (first chunk of 64 sublists)
+    int cnt_first = 0;             // list length of sublist `l5` (first chunk of 32 sublists)
     float top_first = -INFINITY;   // and the largest key in it
-    for (int sid = lane; sid < nsub; sid += 64) {
+    for (int sid = l5; sid < nsub; sid += 32) {
+        if (!live) continue;
         const CoarsePart cp = part[sub_index(sid)];
         T2 = fmaxf(fmaxf(T2, cp.t2), fminf(T1, cp.t1));
         T1 = fmaxf(T1, cp.t1);
-        if (sid == lane) {
+        if (sid == l5) {
             cnt_first = cp.count;
             top_first = cp.t1;
         }
     }
-    if (lane * 4 < DIMP) *reinterpret_cast<float4*>(&s_a[wave][lane * 4]) = apiece;
+#pragma unroll
+    for (int k = 0; k < AP; ++k) {
+        const int piece = l5 + 32 * k;
+        if (piece * 4 < DIMP) *reinterpret_cast<float4*>(&s_a[wave][half][piece * 4]) = apiece[k];
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
+    for (int m = 1; m < 32; m <<= 1) {
         const float o1 = __shfl_xor(T1, m), o2 = __shfl_xor(T2, m);
         T2 = fmaxf(fmaxf(T2, o2), fminf(T1, o1));
         T1 = fmaxf(T1, o1);
@@ -608,16 +622,16 @@ __device__ __forceinline__ void rerank_body(const CoarseProblem& P,
 
     Best2 best;
     best.s1 = -INFINITY; best.s2 = -INFINITY; best.r1 = -1; best.r2 = -1;
-    int npending = 0;   // wave-uniform: rows waiting in `rows`
-    // Sixteen lanes per surviving row, four rows at a time: lane `sub` of a group holds columns
+    int npending = 0;   // rows of this half's query waiting in `rows` (the same in every lane of the half)
+    // Sixteen lanes per surviving row, two rows of either query at a time: lane `sub` of a group holds columns
     // [sub * DIMP/16, (sub + 1) * DIMP/16) of the row and of the query, and the k-ascending chain runs through the
     // group's lanes in order, handed on by a move within the row of sixteen lanes.
-    const int sub = lane & 15, grp = lane >> 4;
-    const float4* a4 = reinterpret_cast<const float4*>(&s_a[wave][0]) + sub * Q;
+    const int sub = lane & 15, gsel = (lane >> 4) & 1;
+    const float4* a4 = reinterpret_cast<const float4*>(&s_a[wave][half][0]) + sub * Q;
     auto flush = [&]() {
-        for (int base = 0; base < npending; base += 4) {
-            const bool act = base + grp < npending;
-            const int row = act ? rows[base + grp] : 0;
+        for (int base = 0; __any(base < npending); base += 2) {
+            const bool act = base + gsel < npending;
+            const int row = act ? rows[base + gsel] : 0;
             const float4* pb = reinterpret_cast<const float4*>(P.rowsB + (size_t)row * DIMP) + sub * Q;
             float4 b[Q];
 #pragma unroll
@@ -627,9 +641,6 @@ __device__ __forceinline__ void rerank_body(const CoarseProblem& P,
 #pragma unroll
             for (int stage = 0; stage < 16; ++stage) {
                 if (sub == stage) {
-                    // the query's columns are read from LDS here, by the lanes whose turn it is, and not kept in
-                    // registers over the sixteen stages (the statement below keeps the compiler from doing that)
-                    asm volatile("" ::: "memory");
 #pragma unroll
                     for (int u = 0; u < Q; ++u) {
                         const float4 a = a4[u];
@@ -651,71 +662,71 @@ __device__ __forceinline__ void rerank_body(const CoarseProblem& P,
         npending = 0;
     };
 
-    for (int chunk = 0; chunk < nsub; chunk += 64) {
-        const int sid = chunk + lane;
+    for (int chunk = 0; chunk < nsub; chunk += 32) {
+        const int sid = chunk + l5;
         // a sublist's largest key is its t1: below the final threshold none of its entries survives
         int cnt = 0;
         if (chunk == 0) {
             cnt = top_first >= thr ? cnt_first : 0;
-        } else if (sid < nsub) {
+        } else if (live && sid < nsub) {
             const CoarsePart cp = part[sub_index(sid)];
             cnt = cp.t1 >= thr ? cp.count : 0;
         }
-        int incl = cnt;   // inclusive prefix sum of the chunk's list lengths
+        int incl = cnt;   // inclusive prefix sum of the chunk's list lengths, per half
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
+        for (int d = 1; d < 32; d <<= 1) {
+            const int o = __shfl_up(incl, d, 32);
+            if (l5 >= d) incl += o;
         }
-        const int total = __shfl(incl, 63);
-        for (int e0 = 0; e0 < total; e0 += 64) {
-            const int e = e0 + lane;
-            // sublist of flat entry e: the first lane whose inclusive prefix exceeds e
+        const int total = __shfl(incl, 31, 32);
+        for (int e0 = 0; __any(e0 < total); e0 += 32) {
+            const int e = e0 + l5;
+            // sublist of flat entry e: the first lane of the half whose inclusive prefix exceeds e
             int lo = 0;
 #pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) {
-                const int probe = __shfl(incl, lo + step - 1);
+            for (int step = 16; step >= 1; step >>= 1) {
+                const int probe = __shfl(incl, lo + step - 1, 32);
                 if (probe <= e) lo += step;
             }
-            lo = min(lo, 63);
-            const int within = e - (__shfl(incl, lo) - __shfl(cnt, lo));
+            lo = min(lo, 31);
+            const int within = e - (__shfl(incl, lo, 32) - __shfl(cnt, lo, 32));
             unsigned ex = 0;   // the entry's rows, if it survives the final threshold
             if (e < total) {
                 const uint2 en = lists[list_slot(sub_index(chunk + lo), within)];
                 if (__uint_as_float(en.y) >= thr) ex = en.x;
             }
             if (!__ballot((ex & 0xffffu) != 0)) continue;
-            const int sid = chunk + lo;
-            const int first_tile = (sid >> 1) * P.tiles_per_split;
+            const int esid = chunk + lo;
+            const int first_tile = (esid >> 1) * P.tiles_per_split;
             // round j queues the j-th named row of every surviving entry (one round, as a rule)
             unsigned bits = ex & 0xffffu;
             while (__ballot(bits != 0)) {
                 const int reg = bits ? __ffs(bits) - 1 : 0;
-                int row = entry_row(ex, reg, sid & 1, first_tile);
+                int row = entry_row(ex, reg, esid & 1, first_tile);
                 const bool keep = bits != 0 && row < nrows_b;
                 if (dblist && keep) row = dblist[row];
                 bits &= bits - 1;
                 const unsigned long long mask = __ballot(keep);
-                const int n = __popcll(mask);
-                if (n == 0) continue;
-                if (npending + n > 64) flush();
-                if (keep) rows[npending + __popcll(mask & ((1ull << lane) - 1ull))] = row;
+                if (!mask) continue;
+                const unsigned mine = (unsigned)(mask >> (32 * half));   // this half's lanes
+                const int n = __popc(mine);
+                if (__any(npending + n > 32)) flush();
+                if (keep) rows[npending + __popc(mine & ((1u << l5) - 1u))] = row;
                 npending += n;
             }
         }
     }
     flush();
 
-    // lanes hold disjoint rows: merge by (score descending, row ascending)
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
+    // the two groups of a half hold disjoint rows: merge by (score descending, row ascending)
+    {
         Best2 o;
-        o.s1 = __shfl_xor(best.s1, m); o.s2 = __shfl_xor(best.s2, m);
-        o.r1 = __shfl_xor(best.r1, m); o.r2 = __shfl_xor(best.r2, m);
+        o.s1 = __shfl_xor(best.s1, 16); o.s2 = __shfl_xor(best.s2, 16);
+        o.r1 = __shfl_xor(best.r1, 16); o.r2 = __shfl_xor(best.r2, 16);
         if (o.r1 >= 0) best2_insert(best, o.s1, o.r1);
         if (o.r2 >= 0) best2_insert(best, o.s2, o.r2);
     }
-    if (lane == 0) {
+    if (live && l5 == 15) {
         const int64_t o = P.out_off + i;
         j1_all[o] = best.r1;
         j2_all[o] = best.r2;
@@ -1117,12 +1128,12 @@ bool launch_bf16_batch(const CoarseProblem* d_probs, int nprobs, int dim, const 
         else if (dimp == 128) hipLaunchKernelGGL(bf16_rerank_group_kernel<128>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
         else hipLaunchKernelGGL(bf16_rerank_group_kernel<256>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
     } else if (by_args) {
-        const dim3 grid(t.rerank_blocks, nprobs), block(kRerankWaves * 64);
+        const dim3 grid((t.rerank_blocks + kRerankPerWave - 1) / kRerankPerWave, nprobs), block(kRerankWaves * 64);
         if (dimp == 64) hipLaunchKernelGGL(bf16_rerank_args_kernel<64>, grid, block, 0, s, *by_args, part, lists, j1, j2, k1, k2);
         else if (dimp == 128) hipLaunchKernelGGL(bf16_rerank_args_kernel<128>, grid, block, 0, s, *by_args, part, lists, j1, j2, k1, k2);
         else hipLaunchKernelGGL(bf16_rerank_args_kernel<256>, grid, block, 0, s, *by_args, part, lists, j1, j2, k1, k2);
     } else {
-        const dim3 grid(t.rerank_blocks, nprobs), block(kRerankWaves * 64);
+        const dim3 grid((t.rerank_blocks + kRerankPerWave - 1) / kRerankPerWave, nprobs), block(kRerankWaves * 64);
         if (dimp == 64) hipLaunchKernelGGL(bf16_rerank_kernel<64>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
         else if (dimp == 128) hipLaunchKernelGGL(bf16_rerank_kernel<128>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
         else hipLaunchKernelGGL(bf16_rerank_kernel<256>, grid, block, 0, s, d_probs, nprobs, part, lists, j1, j2, k1, k2);
