@@ -32,8 +32,8 @@ python3 $root/tools/make_sift_dir.py $dir --images 1000 --features 8192 > /dev/n
 } > $out/${tag}_cli_cfg3_two_contexts_end_to_end.log
 {
   # the sliced map-database query through the C++ host (RCCL all-gather with one rank on this box): one slice, eight slices
-  timeout -k 10 300 $root/visual_slam_amd/vsm_query_db --synthetic 16384,1000000,256 --slices 1 --reps 5 2>&1 | tail -1
-  timeout -k 10 300 $root/visual_slam_amd/vsm_query_db --synthetic 16384,1000000,256 --slices 8 --reps 5 2>&1 | tail -1
+  timeout -k 10 300 $root/visual_slam_amd/vsm_query_db --synthetic 16384,1000000,256 --slices 1 --reps 5 2>&1 | grep "queries x"
+  timeout -k 10 300 $root/visual_slam_amd/vsm_query_db --synthetic 16384,1000000,256 --slices 8 --reps 5 2>&1 | grep "queries x"
 } > $out/${tag}_cli_query_db.log
 rm -rf $dir /tmp/matching.txt /tmp/matching2.txt /tmp/verified.txt /tmp/m2.txt /tmp/v2.txt
 cat $out/${tag}_cli_cfg3_*.log

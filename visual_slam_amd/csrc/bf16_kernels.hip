@@ -419,7 +419,8 @@ __device__ __forceinline__ void coarse_body(const CoarseProblem& P, const int L,
                 }
             }
             const int rel = tile - t0;
-            if (shared_q && ((rel & 31) == 31 || rel == 3 || rel == 7 || rel == 15)) {
+            // (not after the split's last tile: the other splits of a search run beside this one and end with it)
+            if (shared_q && ((rel & 31) == 31 || rel == 3 || rel == 7 || rel == 15) && tile + 1 < t1e) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
                     if (!live[rb]) continue;
