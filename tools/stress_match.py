@@ -1,7 +1,7 @@
 """Longer randomised comparison of the GPU matcher with the CPU oracle than the test suite runs: data built to
 hit ties and undecidable cases (descriptors quantised to a few values, many exact duplicates, clustered rows,
 tiny value ranges), sizes across chunk and merge boundaries, both forms of the u8 query pass, every reverse-search
-mode of the float pair path.  Bit-exact or it stops.   usage: python tools/stress_match.py [--seeds N] [--first K]"""
+mode of the float pair path, single float pairs per call and raw float 2-NN searches.  Bit-exact or it stops.   usage: python tools/stress_match.py [--seeds N] [--first K]"""
 import argparse
 import os
 import sys
@@ -156,6 +156,51 @@ def one_f32_list(m, rng):
             m.release(s)
 
 
+def one_f32_pair(m, rng):
+    """One float pair per call (its searches travel as kernel arguments, cut into up to 32 splits) and a raw 2-NN search
+    over the same sets; a long run of such calls also exercises what one call leaves zeroed for the next."""
+    dim = int(rng.choice([32, 64, 100, 128, 256]))
+    r = rng.random()
+    n0 = int(rng.integers(1, 600)) if r < 0.3 else int(rng.integers(600, 6000))
+    n1 = int(rng.integers(1, 600)) if rng.random() < 0.3 else int(rng.integers(600, 7000))
+    a, b = synth.unit_f32(n0, dim, rng), synth.unit_f32(n1, dim, rng)
+    k = min(n0, n1) // 2
+    if k:
+        noisy = a[rng.choice(n0, k, replace=False)] + float(rng.uniform(0, 0.08)) * rng.standard_normal((k, dim)).astype(np.float32)
+        b[rng.choice(n1, k, replace=False)] = noisy / np.linalg.norm(noisy, axis=1, keepdims=True)
+    if rng.random() < 0.3 and n1 > 40:
+        b[rng.integers(0, n1, int(rng.integers(2, 40)))] = b[0]           # exact duplicates: ties, many survivors
+    if rng.random() < 0.2 and n0 > 4:
+        a[rng.integers(0, n0, 4)] = b[int(rng.integers(0, n1))]
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    metric = vsm.METRIC_DOT if rng.random() < 0.6 else vsm.METRIC_L2
+    ratio = (3, 4) if metric == vsm.METRIC_L2 and rng.random() < 0.6 else None
+    mutual = bool(rng.random() < 0.8)
+    thr = float(rng.choice([-np.inf, -np.inf, 0.0, 0.3, 0.7]))
+    m.set_f32_reverse(int(rng.integers(0, 3)))
+    s0, s1 = m.upload_f32(a), m.upload_f32(b)
+    try:
+        prm = orc.params(ratio, mutual, min_score=thr)
+        o0, o1, ob, _ = orc.match_dense_f32(a, b, metric, prm)
+        sel = np.nonzero(o0 >= 0)[0]
+        ok = True
+        for _ in range(int(rng.integers(1, 4))):                           # the same call again: left-clean state
+            g0, g1, gd = m.match_pair(s0, s1, ratio=(0.75 if ratio else None), mutual=mutual, metric=metric, min_score=thr,
+                                      return_dist=True)
+            ok = ok and np.array_equal(g0, sel) and np.array_equal(g1, o0[sel]) and np.array_equal(gd, ob[sel])
+        d0, d1 = m.match_pair_dense(s0, s1, ratio=(0.75 if ratio else None), mutual=mutual, metric=metric, min_score=thr)
+        ok = ok and np.array_equal(d0, o0) and np.array_equal(d1, o1)
+        gi1, gi2, gk1, gk2 = m.knn2(s0, s1, metric, want_idx2=True)
+        oi, ok1, ok2 = orc.knn2_f32(a, b, metric)
+        ok = ok and np.array_equal(gi1, oi) and np.array_equal(gk1, ok1) and np.array_equal(gk2, ok2)
+        return ok, "f32 pair n0=%d n1=%d dim=%d metric=%d ratio=%s mutual=%d thr=%g matches=%d" % (
+            n0, n1, dim, metric, ratio, mutual, thr, len(sel))
+    finally:
+        m.set_f32_reverse(vsm.F32_REVERSE_AUTO)
+        m.release(s0)
+        m.release(s1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=200)
@@ -163,7 +208,7 @@ def main():
     a = ap.parse_args()
     m = vsm.Matcher(0)
     t0 = time.time()
-    kinds = [one_u8, one_u8, one_u8_list, one_f32_list]
+    kinds = [one_u8, one_u8, one_u8_list, one_f32_list, one_f32_pair]
     for seed in range(a.first, a.first + a.seeds):
         rng = np.random.default_rng(70000 + seed)
         ok, what = kinds[seed % len(kinds)](m, rng)
