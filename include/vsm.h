@@ -115,6 +115,8 @@ int vsm_last_f32_reverse(const vsm_ctx* ctx);
  *     pass knows the runner-up distance only up to ties.
  *     In a submission of eight pairs or more whose sets all have at most 8192 rows, the settling of a strip of 512
  *     query rows runs in the tail of the query kernel itself, while the train image is still in the cache.
+ *     A call with ONE pair of modest size (rows x rows up to 2^29) runs the packed form: such a call is bound by its
+ *     launches, of which that form has fewer.
  *   VSM_U8_PACKED: the packed form only (value and row in one key for every distance).
  *   VSM_U8_TILE_SEPARATE / VSM_U8_TILE_FUSED: as VSM_U8_AUTO, with the settling always in passes of its own /
  *     in the query kernel's tail whenever the sets' sizes allow it, whatever the number of pairs, and without

@@ -255,9 +255,13 @@ def test_tile_minimum_path_is_the_one_that_runs(matcher, u8_mode):
     a, b = synth.sift_pair(600, 900, seed=17)
     s0, s1 = matcher.upload_u8(a), matcher.upload_u8(b)
     try:
+        # 0: tile-minimum, 1: packed, 2: tile-minimum with the tail.  The default mode sends ONE pair of modest size
+        # per call to the packed form (fewer launches), and lists to the tile-minimum form
         matcher.match_pair(s0, s1, ratio=0.8, mutual=True)
-        assert matcher.last_u8_path() == {0: 0, 1: 1, 3: 2}[u8_mode]   # 0: tile-minimum, 1: packed, 2: tile-minimum with the tail
-        matcher.match_pair(s0, s1, ratio=None, mutual=True)
+        assert matcher.last_u8_path() == {0: 1, 1: 1, 3: 2}[u8_mode]
+        matcher.match_pairs([[s0, s1], [s1, s0]], ratio=0.8, mutual=True)
+        assert matcher.last_u8_path() == {0: 0, 1: 1, 3: 2}[u8_mode]
+        matcher.match_pairs([[s0, s1], [s1, s0]], ratio=None, mutual=True)
         assert matcher.last_u8_path() == {0: 0, 1: 1, 3: 2}[u8_mode]   # no ratio test: every row is resolved from its group
         matcher.knn2(s0, s1)
         assert matcher.last_u8_path() == 1                # raw 2-NN: the packed form in every mode
@@ -543,7 +547,7 @@ def test_all_ones_and_duplicate_sets_take_the_rescan_pass(matcher, u8_mode):
             np.testing.assert_array_equal(g0, o0)
             np.testing.assert_array_equal(g1, o1)
             np.testing.assert_array_equal(gd, od)
-            if u8_mode != 1:
+            if u8_mode == 3:   # (the default mode sends one small pair per call to the packed form)
                 assert matcher.last_u8_rescanned() > len(imgs[0]) // 2
         finally:
             for s in ids:
@@ -564,9 +568,9 @@ def test_default_mode_goes_to_the_packed_form_after_a_submission_of_duplicates(m
         assert matcher.last_u8_path() == {0: 0, 1: 1, 3: 2}[u8_mode]
         assert matcher.last_u8_rescanned() == (0 if u8_mode == 1 else 8 * 2048)
         for k in range(33):
-            g0, g1 = matcher.match_pair(ids[2], ids[3], ratio=0.8, mutual=True)
-            np.testing.assert_array_equal(g0, o0)
-            np.testing.assert_array_equal(g1, o1)
+            off, g0, g1 = matcher.match_pairs([[ids[2], ids[3]]] * 2, ratio=0.8, mutual=True)
+            np.testing.assert_array_equal(g0[:off[1]], o0)
+            np.testing.assert_array_equal(g1[:off[1]], o1)
             want = 1 if (u8_mode == 0 and k < 31) else tile
             assert matcher.last_u8_path() == want, "submission %d after the duplicates ran form %d" % (k, matcher.last_u8_path())
     finally:

@@ -13,7 +13,7 @@ from visual_slam_amd import synth  # noqa: E402
 m = vsm.Matcher(0)
 a, b = synth.sift_pair(8192, 8192, seed=1)
 s0, s1 = m.upload_u8(a), m.upload_u8(b)
-for mode, name in ((vsm.U8_AUTO, "tile-minimum"), (vsm.U8_PACKED, "packed")):
+for mode, name in ((vsm.U8_AUTO, "default"), (vsm.U8_TILE_SEPARATE, "tile-minimum"), (vsm.U8_PACKED, "packed")):
     m.set_u8_mode(mode)
     for _ in range(20):
         m.match_pair(s0, s1, ratio=0.8, mutual=True)

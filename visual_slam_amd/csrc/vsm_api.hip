@@ -342,6 +342,13 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
         --c->u8_packed_left;
         tile_path = false;
     }
+    if (tile_path && c->u8_mode == VSM_U8_AUTO && npairs == 1 && nitems > 0 &&
+        (double)pl.pairs[0].nA * (double)pl.pairs[0].nB <= (double)(1 << 29)) {
+        // One pair of modest size per call is bound by its launches, and the packed form queues eight where the
+        // tile-minimum form queues twelve (83 against 117 us on the stream for 8192 x 8192); the faster query pass
+        // pays from some 23 000 x 23 000 rows on.
+        tile_path = false;
+    }
     if (tile_path) HIPCHK(c, c->d_rr3.ensure(rows * 4));   // third array of the rescan pass's per-(chunk, slot) results
     c->R().u8_stats = true;
     c->R().tile_path = tile_path && nitems > 0;
@@ -380,11 +387,19 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     SiftItem* const d_items = reinterpret_cast<SiftItem*>(c->d_pairs.as<char>() + pairs_bytes);
     if (npairs) memcpy(c->R().h_pairs.p, pl.pairs.data(), sizeof(SiftPair) * npairs);
     if (nitems) memcpy(c->R().h_pairs.as<char>() + pairs_bytes, pl.items.data(), sizeof(SiftItem) * nitems);
-    if (npairs)
+    if (npairs == 1)
+        // one pair: its record travels as a kernel argument and its work items are written on the device (a copy
+        // command costs such a call more than ten microseconds on the stream, a small kernel three)
+        launch_sift_plan_single(pl.pairs[0], c->d_pairs.as<SiftPair>(), d_items, c->stream);
+    else if (npairs)
         HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->R().h_pairs.p, nitems ? pairs_bytes + sizeof(SiftItem) * nitems : sizeof(SiftPair) * npairs,
                                  hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(c->R().staged, c->stream));
-    c->R().staged_recorded = true;
+    if (npairs == 1) {
+        c->R().staged_recorded = false;   // nothing was staged: no event on the stream either
+    } else {
+        HIPCHK(c, hipEventRecord(c->R().staged, c->stream));
+        c->R().staged_recorded = true;
+    }
 
     c->R().ev_valid = false;
     c->timing_slot = c->rs;
