@@ -86,7 +86,9 @@ void f32_accept_kernel(const SiftPair* __restrict__ pairs, const F32PairRef* __r
         __syncthreads();   // this block wrote every word the segments name (or an earlier kernel did)
         int base = 0;
         for (int k = 0; k < copy_out.n; ++k) {
-            for (int i = tid; i < copy_out.count[k]; i += 1024) copy_dst[base + i] = copy_out.src[k][i];
+            // (of a match list only the matches: fewer words across the bus; its place in copy_dst stays count[k] wide)
+            const int words = (copy_out.lists >> k) & 1u ? min(copy_out.count[k], base_s) : copy_out.count[k];
+            for (int i = tid; i < words; i += 1024) copy_dst[base + i] = copy_out.src[k][i];
             base += copy_out.count[k];
         }
     }

@@ -1346,19 +1346,21 @@ int f32_single_pair_fast(vsm_ctx* c, const DescSet* A, const DescSet* B, int set
     void* dst_host[8];
     int flag_host = 0, cnt_host = 0;
     auto list_words = [&](WordSegments* sg) {   // run once the device buffers exist
-        auto add = [&](const void* src, int words, void* host) {
+        auto add = [&](const void* src, int words, void* host, bool list = false) {
             if (words <= 0) return;
             sg->src[sg->n] = static_cast<const uint32_t*>(src);
             sg->count[sg->n] = words;
+            if (list) sg->lists |= 1u << sg->n;
             dst_host[sg->n] = host;
             ++sg->n;
         };
         sg->n = 0;
+        sg->lists = 0;
         add(c->flag_dev, 1, &flag_host);
         add(c->d_counts.p, 1, &cnt_host);
-        if (idx0) add(c->d_slot0.p, take, idx0);
-        if (idx1) add(c->d_slot1.p, take, idx1);
-        if (dist) add(c->d_slotd.p, take, dist);
+        if (idx0) add(c->d_slot0.p, take, idx0, true);
+        if (idx1) add(c->d_slot1.p, take, idx1, true);
+        if (dist) add(c->d_slotd.p, take, dist, true);
         if (dense0) add(c->d_dense0.p, A->n, dense0);
         if (dense1) add(c->d_dense1.p, B->n, dense1);
         seg = *sg;
@@ -1401,8 +1403,9 @@ int f32_single_pair_fast(vsm_ctx* c, const DescSet* A, const DescSet* B, int set
     if (!seen) HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     const uint32_t* got = c->h_gather.as<uint32_t>();
-    for (int k = 0; k < seg.n; ++k) {
-        memcpy(dst_host[k], got, (size_t)seg.count[k] * 4);
+    for (int k = 0; k < seg.n; ++k) {   // flag and count come first
+        const int words = (seg.lists >> k) & 1u ? std::min(seg.count[k], std::max(cnt_host, 0)) : seg.count[k];
+        memcpy(dst_host[k], got, (size_t)words * 4);
         got += seg.count[k];
     }
     if (flag_host != 0) {

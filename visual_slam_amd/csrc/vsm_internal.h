@@ -190,6 +190,7 @@ struct WordSegments {
     const uint32_t* src[8];
     int count[8];
     int n;
+    unsigned lists;   // bit k: segment k is a match list, of which only the pair's match count of words matter
 };
 // What a one-pair call leaves zeroed for the next one, so that the next needs no fill command in front of its
 // searches: the words the splits of its searches shared, and the survivor-overflow flag once it has been copied out.
