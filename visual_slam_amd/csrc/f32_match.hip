@@ -167,22 +167,26 @@ void launch_f32_confirm(const SiftPair* pairs, const F32PairRef* refs, int npair
     hipLaunchKernelGGL(f32_confirm_kernel, dim3(npairs), dim3(1024), 0, s, pairs, refs, j1, out);
 }
 
-__global__ void gather_words_kernel(WordSegments seg, uint32_t* __restrict__ dst)
+// list_total (may be NULL): of the segments marked as match lists only *list_total words are copied (a count that
+// exists on the device only); every segment keeps its place, count[k] words wide, in dst.
+__global__ void gather_words_kernel(WordSegments seg, uint32_t* __restrict__ dst, const int64_t* __restrict__ list_total)
 {
+    const long long listed = list_total ? *list_total : INT32_MAX;
     int base = 0;
     for (int k = 0; k < seg.n; ++k) {
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < seg.count[k]; i += gridDim.x * blockDim.x)
+        const int words = (seg.lists >> k) & 1u ? (int)min((long long)seg.count[k], listed) : seg.count[k];
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x)
             dst[base + i] = seg.src[k][i];
         base += seg.count[k];
     }
 }
 
-void launch_gather_words(const WordSegments& seg, uint32_t* dst, hipStream_t s)
+void launch_gather_words(const WordSegments& seg, uint32_t* dst, hipStream_t s, const int64_t* list_total)
 {
     int total = 0;
     for (int k = 0; k < seg.n; ++k) total += seg.count[k];
     if (total <= 0) return;
-    hipLaunchKernelGGL(gather_words_kernel, dim3(std::min(64, (total + 255) / 256)), dim3(256), 0, s, seg, dst);
+    hipLaunchKernelGGL(gather_words_kernel, dim3(std::min(64, (total + 255) / 256)), dim3(256), 0, s, seg, dst, list_total);
 }
 
 // ---- merge of per-slice 2-NN lists (database cut into contiguous row ranges) ---------------

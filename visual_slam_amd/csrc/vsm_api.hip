@@ -143,6 +143,11 @@ struct vsm_ctx {
     struct ResultSlot {
         DevBuf d_offsets, d_tight0, d_tight1;
         HostBuf h_pairs, h_off;
+        // A small u8 submission brings offsets and both lists to this pinned block itself (one kernel behind the
+        // pack kernel, in front of the `packed` event): collecting it then costs no trip to the device at all.
+        // Layout: [offsets and the two rescan counters: 2 * (npairs + 2) words][idx0: rows0 words][idx1: rows0 words]
+        HostBuf h_res;
+        bool res_on_host = false;
         hipEvent_t packed = nullptr;
         hipEvent_t staged = nullptr;    // the slot's pinned staging buffers have been copied to the device
         bool staged_recorded = false;
@@ -631,6 +636,7 @@ extern "C" void vsm_destroy(vsm_ctx* c)
         r.d_tight1.release();
         r.h_pairs.release();
         r.h_off.release();
+        r.h_res.release();
         if (r.packed) (void)hipEventDestroy(r.packed);
         if (r.staged) (void)hipEventDestroy(r.staged);
     }
@@ -1329,6 +1335,9 @@ int f32_pairs_fast(vsm_ctx* c, const int32_t* pairs, int npairs, const vsm_param
 // the flag is looked at after the one synchronisation.  Returns the match count, a VSM_E* code, or
 // kNotDone when the context is in f32-only mode or a survivor list overflowed.
 constexpr int kNotDone = -1000;
+// submissions up to this size hand their result to pinned host memory themselves (see ResultSlot::h_res)
+constexpr int kSmallResultPairs = 4096;
+constexpr size_t kSmallResultRows = 262144;
 int f32_single_pair_fast(vsm_ctx* c, const DescSet* A, const DescSet* B, int set0, int set1, const vsm_params* p,
                          int metric, int32_t* idx0, int32_t* idx1, float* dist, int cap, int32_t* dense0,
                          int32_t* dense1)
@@ -1609,6 +1618,7 @@ extern "C" int vsm_submit_pairs(vsm_ctx* c, const int32_t* pairs, int npairs, co
     const int slot = (c->inflight_head + c->inflight) & 1;
     const int timing_slot_before = c->timing_slot;
     c->rs = slot;
+    c->R().res_on_host = false;
     if (slot == c->last_slot) c->last_npairs = -1;   // the lists of the last collected submission are about to be overwritten
     const DescSet* first = npairs > 0 ? get_set(c, pairs[0]) : nullptr;
     bool on_host = false;
@@ -1629,6 +1639,19 @@ extern "C" int vsm_submit_pairs(vsm_ctx* c, const int32_t* pairs, int npairs, co
         if ((rc = plan_u8(c, pairs, npairs, pl)) != VSM_OK) return rc;
         RunOpts o;
         if ((rc = run_u8(c, pl, make_rule(p), o)) != VSM_OK) return rc;
+        if (npairs > 0 && npairs <= kSmallResultPairs && pl.out0 <= kSmallResultRows) {
+            vsm_ctx::ResultSlot& R = c->R();
+            const size_t off_words = 2 * ((size_t)npairs + 2), rows0 = std::max<size_t>(pl.out0, 1);
+            HIPCHK(c, R.h_res.ensure((off_words + 2 * rows0) * 4));
+            WordSegments seg{};
+            seg.src[0] = R.d_offsets.as<uint32_t>(); seg.count[0] = (int)off_words;
+            seg.src[1] = R.d_tight0.as<uint32_t>(); seg.count[1] = (int)rows0;
+            seg.src[2] = R.d_tight1.as<uint32_t>(); seg.count[2] = (int)rows0;
+            seg.n = 3;
+            seg.lists = 6;
+            launch_gather_words(seg, R.h_res.as<uint32_t>(), c->stream, R.d_offsets.as<int64_t>() + npairs);
+            R.res_on_host = true;
+        }
     }
     HIPCHK(c, hipEventRecord(c->R().packed, c->stream));
     c->timing_slot = timing_slot_before;   // the brackets become readable once this submission is collected
@@ -1653,6 +1676,21 @@ extern "C" long long vsm_collect_matches(vsm_ctx* c, int64_t* offsets, int32_t* 
     vsm_ctx::ResultSlot& R = c->R();
     HIPCHK(c, hipEventSynchronize(R.packed));
     const bool stats = R.u8_stats && !c->inflight_on_host[slot];
+    if (R.res_on_host) {   // everything is in pinned memory already
+        const int64_t* off = R.h_res.as<int64_t>();
+        if (stats) note_u8_stats(c, reinterpret_cast<const int32_t*>(off + npairs + 1));
+        const long long got = off[npairs];
+        c->last_npairs = npairs;
+        c->last_total = got;
+        c->last_slot = slot;
+        if (got > cap) return fail(c, VSM_ECAP, "%lld matches do not fit a buffer of %lld", got, cap);
+        const size_t off_words = 2 * ((size_t)npairs + 2), rows0 = std::max<size_t>(R.rows0, 1);
+        const uint32_t* words = R.h_res.as<uint32_t>();
+        if (got > 0 && idx0) memcpy(idx0, words + off_words, sizeof(int32_t) * got);
+        if (got > 0 && idx1) memcpy(idx1, words + off_words + rows0, sizeof(int32_t) * got);
+        memcpy(offsets, off, sizeof(int64_t) * (npairs + 1));
+        return got;
+    }
     HIPCHK(c, R.h_off.ensure(sizeof(int64_t) * (npairs + 2)));
     HIPCHK(c, hipMemcpyAsync(R.h_off.p, R.d_offsets.p, sizeof(int64_t) * (npairs + (stats ? 2 : 1)), hipMemcpyDeviceToHost, c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));

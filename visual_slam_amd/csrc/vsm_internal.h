@@ -290,7 +290,8 @@ void launch_sift_verify(const SiftPair* pairs, int npairs, SiftItem* vitems, int
 void launch_sift_confirm(const SiftPair* pairs, int npairs, SiftCandidates cand, int mutual,
                          SiftOutputs out, hipStream_t s);
 // counts[npairs] -> offsets[npairs+1] (exclusive scan), then slots -> tight arrays
-void launch_gather_words(const WordSegments& seg, uint32_t* dst, hipStream_t s);
+// list_total (device, may be NULL): segments marked as match lists are copied up to that many words only
+void launch_gather_words(const WordSegments& seg, uint32_t* dst, hipStream_t s, const int64_t* list_total = nullptr);
 
 // ---- geometric verification of putative matches -----------------------------------------
 struct GeomPair {
