@@ -193,6 +193,37 @@ def test_many_submissions_in_flight(matcher):
         matcher.release(s)
 
 
+def test_submission_too_large_to_bring_its_own_lists(matcher):
+    """Small submissions copy offsets and lists to pinned host memory themselves; one with more than 262144 image-0 rows
+    leaves them to copy commands on the second stream.  Both must hand back the same lists."""
+    rng = np.random.default_rng(15)
+    base = synth.sift_like(3000, rng)
+    imgs = []
+    for n in (7000, 7100, 6900, 7050):
+        x = synth.sift_like(n, rng)
+        rows = rng.choice(n, 2500, replace=False)
+        x[rows] = np.clip(base[rng.choice(3000, 2500, replace=False)].astype(np.int32) + rng.integers(-3, 4, (2500, 128)), 0, 255).astype(np.uint8)
+        imgs.append(x)
+    ids = [matcher.upload_u8(x) for x in imgs]
+    pairs = [(i, j) for i in range(4) for j in range(4) if i != j] * 4          # 48 pairs, 336 000 image-0 rows
+    few = pairs[:12]                                                            # 84 000 rows: the pinned block
+    try:
+        off, i0, i1 = matcher.match_pairs([[ids[i], ids[j]] for i, j in pairs])
+        soff, s0, s1 = matcher.match_pairs([[ids[i], ids[j]] for i, j in few])
+        assert off[-1] == len(i0) and soff[-1] == len(s0) and off[-1] > 48 * 1000
+        for k, (i, j) in enumerate(few):
+            o0, o1, _ = orc.match_u8(imgs[i], imgs[j], orc.params((4, 5), True))
+            for o, a0, a1 in ((off, i0, i1), (soff, s0, s1)):
+                np.testing.assert_array_equal(a0[o[k]:o[k + 1]], o0)
+                np.testing.assert_array_equal(a1[o[k]:o[k + 1]], o1)
+        for k in range(12, 48):                                                 # the repeats of the same twelve pairs
+            np.testing.assert_array_equal(i0[off[k]:off[k + 1]], i0[off[k % 12]:off[k % 12 + 1]])
+            np.testing.assert_array_equal(i1[off[k]:off[k + 1]], i1[off[k % 12]:off[k % 12 + 1]])
+    finally:
+        for s in ids:
+            matcher.release(s)
+
+
 def test_full_size_pair_8192(matcher):
     """The benchmark's pair shape, checked element for element."""
     a, b = synth.sift_pair(8192, 8192, seed=14)
