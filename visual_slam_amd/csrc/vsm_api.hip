@@ -148,6 +148,8 @@ struct vsm_ctx {
         // Layout: [offsets and the two rescan counters: 2 * (npairs + 2) words][idx0: rows0 words][idx1: rows0 words]
         HostBuf h_res;
         bool res_on_host = false;
+        size_t res_rows0 = 0;   // width of the two list segments in h_res
+        int res_pairs = 0;
         hipEvent_t packed = nullptr;
         hipEvent_t staged = nullptr;    // the slot's pinned staging buffers have been copied to the device
         bool staged_recorded = false;
@@ -920,6 +922,39 @@ int queue_coarse(vsm_ctx* c, std::vector<CoarseProblem>& probs, int dim, size_t 
 }
 
 // reads the overflow flag of the last queue_coarse (synchronises the stream)
+// submissions up to this size hand their result to pinned host memory themselves (see ResultSlot::h_res)
+constexpr int kSmallResultPairs = 4096;
+constexpr size_t kSmallResultRows = 262144;
+constexpr size_t kSmallResultRowsF32 = 1 << 21;   // float lists are thin (a score floor, a mutual check): more rows
+
+// Queues, behind the pack kernel of the submission in the current slot, the kernel that copies [offsets and the two
+// counters behind them][idx0][idx1][flag word] to the slot's pinned block; only as many list words as there are
+// matches (a count the device has) cross the bus.  flag (may be NULL): a device word to bring along, e.g. the
+// survivor-overflow flag of a float submission.  No-op for submissions above the limits.
+int queue_small_result(vsm_ctx* c, int npairs, size_t out0, size_t row_limit, const int* flag)
+{
+    vsm_ctx::ResultSlot& R = c->R();
+    R.res_on_host = false;
+    if (npairs <= 0 || npairs > kSmallResultPairs || out0 > row_limit) return VSM_OK;
+    const size_t off_words = 2 * ((size_t)npairs + 2), rows0 = std::max<size_t>(out0, 1);
+    HIPCHK(c, R.h_res.ensure((off_words + 2 * rows0 + 1) * 4));
+    WordSegments seg{};
+    seg.src[0] = R.d_offsets.as<uint32_t>(); seg.count[0] = (int)off_words;
+    seg.src[1] = R.d_tight0.as<uint32_t>(); seg.count[1] = (int)rows0;
+    seg.src[2] = R.d_tight1.as<uint32_t>(); seg.count[2] = (int)rows0;
+    seg.n = 3;
+    seg.lists = 6;
+    if (flag) {
+        seg.src[3] = reinterpret_cast<const uint32_t*>(flag); seg.count[3] = 1;
+        seg.n = 4;
+    }
+    launch_gather_words(seg, R.h_res.as<uint32_t>(), c->stream, R.d_offsets.as<int64_t>() + npairs);
+    R.res_on_host = true;
+    R.res_rows0 = rows0;
+    R.res_pairs = npairs;
+    return VSM_OK;
+}
+
 int coarse_overflowed(vsm_ctx* c, bool* overflow)
 {
     int* flag = c->h_small.as<int>() + 8;
@@ -1320,7 +1355,17 @@ int f32_pairs_fast(vsm_ctx* c, const int32_t* pairs, int npairs, const vsm_param
     if (rc) return rc;
     if ((rc = run_f32_batch(c, pl, make_f32_rule(p, metric), o)) != VSM_OK) return rc;
     bool overflow = false;
-    if ((rc = coarse_overflowed(c, &overflow)) != VSM_OK) return rc;
+    // a small submission brings offsets, lists and the overflow flag to pinned memory in one kernel: one wait, and
+    // nothing left to copy when the lists are asked for
+    if (o.want_pack && npairs > 0 && (rc = queue_small_result(c, npairs, pl.out0, kSmallResultRowsF32, c->flag_dev)) != VSM_OK) return rc;
+    if (c->R().res_on_host) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        overflow = c->R().h_res.as<uint32_t>()[2 * ((size_t)npairs + 2) + 2 * c->R().res_rows0] != 0;
+        if (overflow) c->R().res_on_host = false;
+    } else if ((rc = coarse_overflowed(c, &overflow)) != VSM_OK) {
+        return rc;
+    }
     if (overflow) {
         c->R().ev_valid = false;
         return VSM_OK;
@@ -1335,9 +1380,6 @@ int f32_pairs_fast(vsm_ctx* c, const int32_t* pairs, int npairs, const vsm_param
 // the flag is looked at after the one synchronisation.  Returns the match count, a VSM_E* code, or
 // kNotDone when the context is in f32-only mode or a survivor list overflowed.
 constexpr int kNotDone = -1000;
-// submissions up to this size hand their result to pinned host memory themselves (see ResultSlot::h_res)
-constexpr int kSmallResultPairs = 4096;
-constexpr size_t kSmallResultRows = 262144;
 int f32_single_pair_fast(vsm_ctx* c, const DescSet* A, const DescSet* B, int set0, int set1, const vsm_params* p,
                          int metric, int32_t* idx0, int32_t* idx1, float* dist, int cap, int32_t* dense0,
                          int32_t* dense1)
@@ -1483,6 +1525,7 @@ extern "C" long long vsm_match_pairs_device(vsm_ctx* c, const int32_t* pairs, in
     const DescSet* first = npairs > 0 ? get_set(c, pairs[0]) : nullptr;
     const bool float_sets = first && first->kind == SET_F32;
     RunOpts o;
+    c->R().res_on_host = false;
     if (float_sets) {
         bool done = false;
         if ((rc = f32_pairs_fast(c, pairs, npairs, p, metric, o, &done)) != VSM_OK) return rc;
@@ -1498,6 +1541,17 @@ extern "C" long long vsm_match_pairs_device(vsm_ctx* c, const int32_t* pairs, in
         Plan pl;
         if ((rc = plan_u8(c, pairs, npairs, pl)) != VSM_OK) return rc;
         if ((rc = run_u8(c, pl, make_rule(p), o)) != VSM_OK) return rc;
+        if ((rc = queue_small_result(c, npairs, pl.out0, kSmallResultRows, nullptr)) != VSM_OK) return rc;
+    }
+    if (c->R().res_on_host) {   // total (and the rescan counters) come with the lists
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        const int64_t* off = c->R().h_res.as<int64_t>();
+        if (!float_sets && c->R().u8_stats) note_u8_stats(c, reinterpret_cast<const int32_t*>(off + npairs + 1));
+        c->last_npairs = npairs;
+        c->last_total = off[npairs];
+        c->last_slot = c->rs;
+        return off[npairs];
     }
     HIPCHK(c, c->h_small.ensure(64));
     long long* tot = c->h_small.as<long long>();
@@ -1519,6 +1573,16 @@ extern "C" long long vsm_fetch_matches(vsm_ctx* c, int64_t* offsets, int32_t* id
     if (!c) return VSM_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     const long long tot = c->last_total;
+    if (c->R().res_on_host && c->R().res_pairs == c->last_npairs && c->last_slot == c->rs) {
+        // the submission brought its lists to pinned memory itself, and whoever set last_total has waited for it
+        if (tot > cap) return fail(c, VSM_ECAP, "%lld matches do not fit a buffer of %lld", tot, cap);
+        const size_t off_words = 2 * ((size_t)c->last_npairs + 2);
+        const uint32_t* words = c->R().h_res.as<uint32_t>();
+        if (offsets) memcpy(offsets, words, sizeof(int64_t) * (c->last_npairs + 1));
+        if (tot > 0 && idx0) memcpy(idx0, words + off_words, sizeof(int32_t) * tot);
+        if (tot > 0 && idx1) memcpy(idx1, words + off_words + c->R().res_rows0, sizeof(int32_t) * tot);
+        return tot;
+    }
     if (offsets) {
         if (c->last_npairs)
             HIPCHK(c, hipMemcpyAsync(offsets, c->R().d_offsets.p, sizeof(int64_t) * (c->last_npairs + 1), hipMemcpyDeviceToHost, c->stream));
@@ -1639,19 +1703,7 @@ extern "C" int vsm_submit_pairs(vsm_ctx* c, const int32_t* pairs, int npairs, co
         if ((rc = plan_u8(c, pairs, npairs, pl)) != VSM_OK) return rc;
         RunOpts o;
         if ((rc = run_u8(c, pl, make_rule(p), o)) != VSM_OK) return rc;
-        if (npairs > 0 && npairs <= kSmallResultPairs && pl.out0 <= kSmallResultRows) {
-            vsm_ctx::ResultSlot& R = c->R();
-            const size_t off_words = 2 * ((size_t)npairs + 2), rows0 = std::max<size_t>(pl.out0, 1);
-            HIPCHK(c, R.h_res.ensure((off_words + 2 * rows0) * 4));
-            WordSegments seg{};
-            seg.src[0] = R.d_offsets.as<uint32_t>(); seg.count[0] = (int)off_words;
-            seg.src[1] = R.d_tight0.as<uint32_t>(); seg.count[1] = (int)rows0;
-            seg.src[2] = R.d_tight1.as<uint32_t>(); seg.count[2] = (int)rows0;
-            seg.n = 3;
-            seg.lists = 6;
-            launch_gather_words(seg, R.h_res.as<uint32_t>(), c->stream, R.d_offsets.as<int64_t>() + npairs);
-            R.res_on_host = true;
-        }
+        if ((rc = queue_small_result(c, npairs, pl.out0, kSmallResultRows, nullptr)) != VSM_OK) return rc;
     }
     HIPCHK(c, hipEventRecord(c->R().packed, c->stream));
     c->timing_slot = timing_slot_before;   // the brackets become readable once this submission is collected
@@ -1684,7 +1736,7 @@ extern "C" long long vsm_collect_matches(vsm_ctx* c, int64_t* offsets, int32_t* 
         c->last_total = got;
         c->last_slot = slot;
         if (got > cap) return fail(c, VSM_ECAP, "%lld matches do not fit a buffer of %lld", got, cap);
-        const size_t off_words = 2 * ((size_t)npairs + 2), rows0 = std::max<size_t>(R.rows0, 1);
+        const size_t off_words = 2 * ((size_t)npairs + 2), rows0 = R.res_rows0;
         const uint32_t* words = R.h_res.as<uint32_t>();
         if (got > 0 && idx0) memcpy(idx0, words + off_words, sizeof(int32_t) * got);
         if (got > 0 && idx1) memcpy(idx1, words + off_words + rows0, sizeof(int32_t) * got);
