@@ -2006,6 +2006,26 @@ extern "C" int vsm_knn2(vsm_ctx* c, int set_q, int set_db, int metric,
     if (kind == SET_F32) {
         F32Result r;
         if ((rc = run_f32_knn(c, A, B, metric, false, &r)) != VSM_OK) return rc;
+        if ((size_t)A->n <= kSmallResultRows) {
+            // the four arrays go to pinned memory end to end in one kernel: one wait instead of four copy commands into
+            // the caller's pageable arrays
+            WordSegments seg{};
+            void* host[4];
+            auto add = [&](const void* src, void* dst) {
+                if (!dst) return;
+                seg.src[seg.n] = static_cast<const uint32_t*>(src);
+                seg.count[seg.n] = A->n;
+                host[seg.n++] = dst;
+            };
+            add(r.j1, idx1); add(r.j2, idx2); add(r.k1, d1); add(r.k2, d2);
+            if (seg.n) {
+                HIPCHK(c, c->h_gather.ensure((size_t)seg.n * A->n * 4));
+                launch_gather_words(seg, c->h_gather.as<uint32_t>(), c->stream);
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                for (int k = 0; k < seg.n; ++k) memcpy(host[k], c->h_gather.as<uint32_t>() + (size_t)k * A->n, (size_t)A->n * 4);
+            }
+            return A->n;
+        }
         if (idx1) HIPCHK(c, hipMemcpyAsync(idx1, r.j1, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
         if (idx2) HIPCHK(c, hipMemcpyAsync(idx2, r.j2, sizeof(int32_t) * A->n, hipMemcpyDeviceToHost, c->stream));
         if (d1) HIPCHK(c, hipMemcpyAsync(d1, r.k1, sizeof(float) * A->n, hipMemcpyDeviceToHost, c->stream));
