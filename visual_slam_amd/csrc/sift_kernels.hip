@@ -305,17 +305,19 @@ void sift_query_kernel(const SiftPair* __restrict__ pairs, const SiftItem* __res
 
 // Pair record and query-pass work items of a one-pair submission, written on the device (the record
 // comes as a kernel argument), for callers that may not copy from host memory.
-__global__ void sift_plan_single_kernel(SiftPair sp, SiftPair* __restrict__ pair_out, SiftItem* __restrict__ items)
+__global__ void sift_plan_single_kernel(SiftPair sp, SiftPair* __restrict__ pair_out, SiftItem* __restrict__ items,
+                                        int32_t* __restrict__ zero_pair)
 {
     if (threadIdx.x == 0) *pair_out = sp;
+    if (zero_pair && threadIdx.x < 2) zero_pair[threadIdx.x] = 0;   // two counters the caller wants cleared: no fill command
     const int n = sp.nstrips * sp.nchunks;
     for (int k = threadIdx.x; k < n; k += blockDim.x)
         items[k] = SiftItem{0, (int16_t)(k / sp.nchunks), (int16_t)(k % sp.nchunks)};
 }
 
-void launch_sift_plan_single(const SiftPair& sp, SiftPair* pair_out, SiftItem* items, hipStream_t s)
+void launch_sift_plan_single(const SiftPair& sp, SiftPair* pair_out, SiftItem* items, hipStream_t s, int32_t* zero_pair)
 {
-    hipLaunchKernelGGL(sift_plan_single_kernel, dim3(1), dim3(256), 0, s, sp, pair_out, items);
+    hipLaunchKernelGGL(sift_plan_single_kernel, dim3(1), dim3(256), 0, s, sp, pair_out, items, zero_pair);
 }
 
 void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,

@@ -397,7 +397,8 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
     if (npairs == 1)
         // one pair: its record travels as a kernel argument and its work items are written on the device (a copy
         // command costs such a call more than ten microseconds on the stream, a small kernel three)
-        launch_sift_plan_single(pl.pairs[0], c->d_pairs.as<SiftPair>(), d_items, c->stream);
+        launch_sift_plan_single(pl.pairs[0], c->d_pairs.as<SiftPair>(), d_items, c->stream,
+                                !(tile_path && nitems > 0) ? d_stats : nullptr);   // (the packed form's rescan counters: zero)
     else if (npairs)
         HIPCHK(c, hipMemcpyAsync(c->d_pairs.p, c->R().h_pairs.p, nitems ? pairs_bytes + sizeof(SiftItem) * nitems : sizeof(SiftPair) * npairs,
                                  hipMemcpyHostToDevice, c->stream));
@@ -491,7 +492,7 @@ int run_u8(vsm_ctx* c, Plan& pl, const MatchRule& rule, const RunOpts& o)
             launch_sift_select(c->d_pairs.as<SiftPair>(), npairs, c->d_rr1.as<int32_t>(),
                                c->d_rrj.as<int32_t>(), c->d_rr2.as<int32_t>(), rule, cand, out, c->stream);
         }
-        if (!tile_path || nitems == 0) HIPCHK(c, hipMemsetAsync(d_stats, 0, 2 * sizeof(int32_t), c->stream));
+        if ((!tile_path || nitems == 0) && npairs != 1) HIPCHK(c, hipMemsetAsync(d_stats, 0, 2 * sizeof(int32_t), c->stream));
         if (nvitems) {
             if (c->timing) HIPCHK(c, hipEventRecord(c->R().ev2, c->stream));
             launch_sift_verify(c->d_pairs.as<SiftPair>(), npairs, d_items + nitems, nvitems,

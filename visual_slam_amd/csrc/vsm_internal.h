@@ -239,7 +239,8 @@ void launch_sift_transform(const uint8_t* des, int n, int n_pad, int8_t* frag, i
                            hipStream_t s);
 // one-pair submission planned on the device: *pair_out = sp (row_off = out0_off = out1_off = 0), items =
 // every (strip, chunk) of it in strip-major order
-void launch_sift_plan_single(const SiftPair& sp, SiftPair* pair_out, SiftItem* items, hipStream_t s);
+// zero_pair (may be NULL): two ints the kernel also clears
+void launch_sift_plan_single(const SiftPair& sp, SiftPair* pair_out, SiftItem* items, hipStream_t s, int32_t* zero_pair = nullptr);
 // query-side pass: per (chunk, query row) best train row, its distance, runner-up distance (INT32_MAX
 // throughout without want_second: a cheaper epilogue for callers that never look at it)
 void launch_sift_query(const SiftPair* pairs, const SiftItem* items, int nitems,
